@@ -1,0 +1,153 @@
+/*
+ * nbls.h — C ABI of libnbls_hip.so: the MI355X (gfx950) narrow-band least-squares /
+ * least-trimmed-squares array processor.
+ *
+ * The reference (amiezzi/narrow_band_least_squares) is pure Python and has no FFI of its
+ * own; this ABI is what a ctypes binding for its hot path binds (INTEGRATION.md shows the
+ * stub).  Each entry point names the reference interface it replaces (file:line relative
+ * to the reference checkout):
+ *
+ *   nbls_set_trace      <- the `st` argument of narrow_band_least_squares()
+ *                          (narrow_band_least_squares.py:8,43) / ltsva() (:91)
+ *   nbls_set_geometry   <- lat_list/lon_list -> rij -> co-array inside ltsva
+ *                          (helpers.py:239-284; lts_array DataBin/LsBeam, source absent)
+ *   nbls_plan           <- the per-band arguments of the band loop
+ *                          (narrow_band_least_squares.py:67-91: filter_data() SOS,
+ *                          WINLEN_list[ii], WINOVER, ALPHA)
+ *   nbls_execute        <- one pass of the band loop body for every planned band:
+ *                          helpers.py:124-139 (filter + taper) and ltsva
+ *                          (narrow_band_least_squares.py:91 / :183)
+ *   nbls_fetch          <- the result rows written at narrow_band_least_squares.py:104-113
+ *                          (vel/baz/mdccm/sigma_tau), the lag vectors tau and the LTS
+ *                          weights that become `stdict` (:114-124)
+ *   nbls_run            <- convenience: plan + execute + sync + fetch
+ *
+ * Conventions: plain pointers and sizes; the caller owns every host buffer; the library
+ * keeps no host pointer after a call returns; every function returns 0 on success or a
+ * negative nbls_status; nbls_last_error() gives the message.  One handle = one GPU = one
+ * host thread at a time.  All floating point is IEEE double.
+ */
+#ifndef NBLS_H
+#define NBLS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbls_handle nbls_handle;
+
+typedef enum {
+    NBLS_OK = 0,
+    NBLS_ERR_ARG = -1,        /* bad shape / NULL pointer / out-of-range parameter   */
+    NBLS_ERR_STATE = -2,      /* call order (no trace / geometry / plan yet)          */
+    NBLS_ERR_GEOMETRY = -3,   /* < 3 elements, < 4 for LTS, rank-deficient co-array   */
+    NBLS_ERR_HIP = -4,        /* HIP runtime failure                                  */
+    NBLS_ERR_NOMEM = -5,      /* device allocation failed                             */
+    NBLS_ERR_UNSUPPORTED = -6 /* size beyond what the kernels are built for           */
+} nbls_status;
+
+/* FAST-LTS parameters (lts_array LTSEstimator / robustbase ltsReg; host computes them). */
+typedef struct {
+    double alpha;           /* subset fraction in [0.5, 1)                              */
+    int32_t h;              /* subset size                                              */
+    int32_t nstarts;        /* number of elemental starts (<= 1024)                     */
+    const int32_t* starts;  /* [nstarts][4] pair indices, -1 padded                     */
+    int32_t csteps;         /* C-steps per start (4)                                    */
+    int32_t csteps2;        /* max C-steps in the refinement (100)                      */
+    int32_t ncand;          /* candidates refined (10, <= 16)                           */
+    double xij_mad[2];      /* 1.4826 * median |xij| per column                         */
+    double raw_factor;      /* raw consistency * small-sample correction factor         */
+    const double* rew_table;/* [npairs+1] reweighted factor by number of unit weights   */
+    double quantile;        /* weight cut-off (qnorm(0.9875))                           */
+    double zero_scale;      /* exact-fit threshold (1e-7)                               */
+} nbls_lts_params;
+
+/* Per-run timing of the three stages, measured with HIP events on the handle's stream. */
+typedef struct {
+    double filter_ms;
+    double xcorr_ms;
+    double solve_ms;
+    double total_ms;
+    int64_t xcorr_launches;
+} nbls_timings;
+
+int nbls_version(void);
+
+/* Create a handle on HIP device `device_id` (lazy HIP init happens here, so it is safe to
+ * fork before the first call).  *out is NULL on failure; nbls_last_error(NULL) explains. */
+int nbls_create(int device_id, nbls_handle** out);
+void nbls_destroy(nbls_handle* h);
+const char* nbls_last_error(const nbls_handle* h);
+
+/* Raw multichannel trace, channel-major contiguous trace[nchans][npts], copied to HBM and
+ * kept resident until the next nbls_set_trace. */
+int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs);
+
+/* Co-array: xij[npairs][2] (km; pair k = (i,j), i<j, lexicographic; xij = r_i - r_j),
+ * pair_idx[npairs][2], xpinv[2][npairs] = pseudo-inverse of xij (OLS). */
+int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx,
+                      const double* xpinv, int32_t npairs);
+
+/* Describe the bands to process.
+ *   sos[nbands][nsections][6]   second-order sections actually applied (a0 == 1);
+ *                               nsections == 0 (sos NULL): the trace is already filtered
+ *                               (ltsva() on a filtered stream), it is only copied/tapered
+ *   zero_phase                  0 causal single pass, 1 forward-backward
+ *   taper_left/right[taper_len] whole-trace taper ramps multiplied onto the first/last samples
+ *   winlen/wininc[nbands]       window length / hop in samples
+ *   vector_len                  row length of the result grids (>= max windows per band)
+ *   lts                         NULL -> ordinary least squares
+ *   xcorr_impl                  0 auto, 1 plain VALU kernel, 2 f64-MFMA kernel
+ */
+int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections,
+              int32_t zero_phase, const double* taper_left, const double* taper_right,
+              int32_t taper_len, const int32_t* winlen, const int32_t* wininc,
+              int32_t vector_len, const nbls_lts_params* lts, int32_t xcorr_impl);
+
+/* Launch the whole pass (filter -> xcorr/lag pick -> MdCCM + OLS|LTS) asynchronously on the
+ * handle's stream; nbls_sync waits for it. */
+int nbls_execute(nbls_handle* h);
+/* Same, restricted to a subset of stages: bit 0 filter, bit 1 xcorr/lag pick, bit 2 solve
+ * (filter only = the reference's filter_data(), helpers.py:108-141). */
+int nbls_execute_stages(nbls_handle* h, int32_t stage_mask);
+int nbls_sync(nbls_handle* h);
+
+/* Copy results to host.  Any pointer may be NULL to skip it.
+ *   vel/baz/mdccm/sigma_tau [nbands][vector_len]   (zeros beyond nwin[b])
+ *   nwin[nbands]
+ *   lag [nbands][vector_len][npairs] int32: tau = lag / fs  (lag = W - 1 - argmax)
+ *   cmax[nbands][vector_len][npairs] normalised cross-correlation maxima
+ *   weights[nbands][vector_len][npairs] uint8 (1 = kept, 0 = dropped by LTS; all 1 for OLS)
+ *   z[nbands][vector_len][2] slowness estimate (s/km) */
+int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* sigma_tau,
+               int32_t* nwin, int32_t* lag, double* cmax, uint8_t* weights, double* z);
+
+/* Copy the filtered+tapered trace of planned band `band` to host: out[nchans][npts]. */
+int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out);
+
+/* Device pointers of the result grids (for an RCCL gather straight from HBM):
+ * ptrs[0..3] = vel, baz, mdccm, sigma_tau (double[nbands][vector_len]); ptrs[4] = nwin (int32). */
+int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid);
+
+/* Enable (1) / disable (0) HIP-event timing of the stages; read the last run's timings. */
+int nbls_set_profiling(nbls_handle* h, int32_t on);
+int nbls_get_timings(nbls_handle* h, nbls_timings* out);
+
+/* plan + execute + sync + fetch in one call. */
+int nbls_run(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections,
+             int32_t zero_phase, const double* taper_left, const double* taper_right,
+             int32_t taper_len, const int32_t* winlen, const int32_t* wininc,
+             int32_t vector_len, const nbls_lts_params* lts, int32_t xcorr_impl,
+             double* vel, double* baz, double* mdccm, double* sigma_tau, int32_t* nwin,
+             int32_t* lag, double* cmax, uint8_t* weights, double* z);
+
+/* Debug / self-test: run one f64 MFMA 16x16x4 on caller data (a[64], b[64] one value per
+ * lane) and return the 256 accumulator values as out[lane*4 + reg]. */
+int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBLS_H */

@@ -1,0 +1,244 @@
+"""ctypes binding of ``libnbls_hip.so`` (C ABI: ``include/nbls.h``).
+
+There is no CPU fallback: if the library is missing or no HIP device can be opened, the
+functions of this package raise.  No PyTorch is involved on this path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libnbls_hip.so')
+
+EXPORTS = [
+    'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
+    'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
+    'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
+    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64',
+]
+
+NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
+NBLS_ERR_HIP, NBLS_ERR_NOMEM, NBLS_ERR_UNSUPPORTED = -4, -5, -6
+
+
+class NblsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libnbls_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+class LtsParams(C.Structure):
+    _fields_ = [
+        ('alpha', C.c_double), ('h', C.c_int32), ('nstarts', C.c_int32),
+        ('starts', C.POINTER(C.c_int32)), ('csteps', C.c_int32), ('csteps2', C.c_int32),
+        ('ncand', C.c_int32), ('xij_mad', C.c_double * 2), ('raw_factor', C.c_double),
+        ('rew_table', C.POINTER(C.c_double)), ('quantile', C.c_double), ('zero_scale', C.c_double),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [('filter_ms', C.c_double), ('xcorr_ms', C.c_double), ('solve_ms', C.c_double),
+                ('total_ms', C.c_double), ('xcorr_launches', C.c_int64)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (once) and return the ctypes library; raises ImportError if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError('%s not found: build it with `make -C %s` (or __graft_entry__.build()); '
+                          'this package has no CPU fallback' % (p, os.path.dirname(p)))
+    lib = C.CDLL(p)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    u8p = C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    lib.nbls_version.restype = C.c_int
+    lib.nbls_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.nbls_destroy.argtypes = [vp]
+    lib.nbls_destroy.restype = None
+    lib.nbls_last_error.argtypes = [vp]
+    lib.nbls_last_error.restype = C.c_char_p
+    lib.nbls_set_trace.argtypes = [vp, dp, C.c_int32, C.c_int64, C.c_double]
+    lib.nbls_set_geometry.argtypes = [vp, dp, ip, dp, C.c_int32]
+    plan_args = [vp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip, ip, C.c_int32,
+                 C.POINTER(LtsParams), C.c_int32]
+    lib.nbls_plan.argtypes = plan_args
+    lib.nbls_execute.argtypes = [vp]
+    lib.nbls_execute_stages.argtypes = [vp, C.c_int32]
+    lib.nbls_sync.argtypes = [vp]
+    fetch_args = [dp, dp, dp, dp, ip, ip, dp, u8p, dp]
+    lib.nbls_fetch.argtypes = [vp] + fetch_args
+    lib.nbls_fetch_filtered.argtypes = [vp, C.c_int32, dp]
+    lib.nbls_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.nbls_set_profiling.argtypes = [vp, C.c_int32]
+    lib.nbls_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.nbls_run.argtypes = plan_args + fetch_args
+    lib.nbls_probe_mfma_f64.argtypes = [vp, dp, dp, dp]
+    for name in EXPORTS:
+        if name not in ('nbls_destroy', 'nbls_last_error'):
+            getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u8ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Handle:
+    """One GPU, one stream, one host thread at a time."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.nbls_create(int(device_id), C.byref(h))
+        if rc != 0:
+            raise NblsError(rc, self.lib.nbls_last_error(None).decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self.nchans = self.npts = self.npairs = 0
+        self.nbands = self.vector_len = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.nbls_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.nbls_last_error(self._h).decode()
+            if rc == NBLS_ERR_GEOMETRY:
+                raise RuntimeError(msg)
+            if rc in (NBLS_ERR_ARG, NBLS_ERR_UNSUPPORTED):
+                raise ValueError(msg)
+            raise NblsError(rc, msg)
+
+    def set_trace(self, data, fs):
+        data = _f64(data)
+        if data.ndim != 2:
+            raise ValueError('trace must be (nchans, npts)')
+        self._chk(self.lib.nbls_set_trace(self._h, _dptr(data), data.shape[0], data.shape[1], float(fs)))
+        self.nchans, self.npts, self.fs = data.shape[0], data.shape[1], float(fs)
+
+    def set_geometry(self, xij, pair_idx, xpinv):
+        xij = _f64(xij)
+        pair_idx = np.ascontiguousarray(pair_idx, dtype=np.int32)
+        xpinv = _f64(xpinv)
+        self._chk(self.lib.nbls_set_geometry(self._h, _dptr(xij), _iptr(pair_idx), _dptr(xpinv), xij.shape[0]))
+        self.npairs = xij.shape[0]
+
+    def plan(self, sos, zero_phase, taper_left, taper_right, winlen, wininc, vector_len, lts=None,
+             xcorr_impl=0):
+        """sos: (B, S, 6) or None (unfiltered single band).  lts: dict from planner.lts_plan()."""
+        winlen = np.ascontiguousarray(winlen, dtype=np.int32)
+        wininc = np.ascontiguousarray(wininc, dtype=np.int32)
+        nb = len(winlen)
+        if sos is None:
+            sos_p, nsec = None, 0
+        else:
+            sos = _f64(sos)
+            if sos.ndim != 3 or sos.shape[0] != nb or sos.shape[2] != 6:
+                raise ValueError('sos must be (nbands, nsections, 6)')
+            sos_p, nsec = _dptr(sos), sos.shape[1]
+        tl = _f64(taper_left if taper_left is not None else np.zeros(0))
+        tr = _f64(taper_right if taper_right is not None else np.zeros(0))
+        if len(tl) != len(tr):
+            raise ValueError('taper ramps must have equal length')
+        lp = None
+        keep = [sos, tl, tr, winlen, wininc]
+        if lts is not None:
+            starts = np.ascontiguousarray(lts['starts'], dtype=np.int32)
+            rew = _f64(lts['rew_table'])
+            p = LtsParams()
+            p.alpha = float(lts['alpha'])
+            p.h = int(lts['h'])
+            p.nstarts = int(starts.shape[0])
+            p.starts = _iptr(starts)
+            p.csteps = int(lts['csteps'])
+            p.csteps2 = int(lts['csteps2'])
+            p.ncand = int(lts['ncand'])
+            p.xij_mad[0] = float(lts['xij_mad'][0])
+            p.xij_mad[1] = float(lts['xij_mad'][1])
+            p.raw_factor = float(lts['raw_factor'])
+            p.rew_table = _dptr(rew)
+            p.quantile = float(lts['quantile'])
+            p.zero_scale = float(lts['zero_scale'])
+            lp = C.byref(p)
+            keep += [starts, rew, p]
+        self._chk(self.lib.nbls_plan(self._h, nb, sos_p, nsec, int(bool(zero_phase)), _dptr(tl), _dptr(tr),
+                                     len(tl), _iptr(winlen), _iptr(wininc), int(vector_len), lp,
+                                     int(xcorr_impl)))
+        self.nbands, self.vector_len = nb, int(vector_len)
+
+    def execute(self, stages=7):
+        self._chk(self.lib.nbls_execute_stages(self._h, int(stages)))
+
+    def sync(self):
+        self._chk(self.lib.nbls_sync(self._h))
+
+    def fetch(self, want_lag=False, want_cmax=False, want_weights=False, want_z=False):
+        B, VL, P = self.nbands, self.vector_len, self.npairs
+        out = dict(vel=np.empty((B, VL)), baz=np.empty((B, VL)), mdccm=np.empty((B, VL)),
+                   sigma_tau=np.empty((B, VL)), nwin=np.empty(B, dtype=np.int32))
+        lag = np.empty((B, VL, P), dtype=np.int32) if want_lag else None
+        cmax = np.empty((B, VL, P)) if want_cmax else None
+        wts = np.empty((B, VL, P), dtype=np.uint8) if want_weights else None
+        z = np.empty((B, VL, 2)) if want_z else None
+        self._chk(self.lib.nbls_fetch(self._h, _dptr(out['vel']), _dptr(out['baz']), _dptr(out['mdccm']),
+                                      _dptr(out['sigma_tau']), _iptr(out['nwin']), _iptr(lag), _dptr(cmax),
+                                      _u8ptr(wts), _dptr(z)))
+        out.update(lag=lag, cmax=cmax, weights=wts, z=z)
+        return out
+
+    def fetch_filtered(self, band):
+        out = np.empty((self.nchans, self.npts))
+        self._chk(self.lib.nbls_fetch_filtered(self._h, int(band), _dptr(out)))
+        return out
+
+    def device_results(self):
+        ptrs = (C.c_void_p * 5)()
+        nbytes = C.c_int64()
+        self._chk(self.lib.nbls_device_results(self._h, ptrs, C.byref(nbytes)))
+        return [p or 0 for p in ptrs], nbytes.value
+
+    def set_profiling(self, on=True):
+        self._chk(self.lib.nbls_set_profiling(self._h, int(bool(on))))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.lib.nbls_get_timings(self._h, C.byref(t)))
+        return dict(filter_ms=t.filter_ms, xcorr_ms=t.xcorr_ms, solve_ms=t.solve_ms,
+                    total_ms=t.total_ms, xcorr_launches=t.xcorr_launches)
+
+    def probe_mfma_f64(self, a, b):
+        a = _f64(a); b = _f64(b)
+        out = np.empty(256)
+        self._chk(self.lib.nbls_probe_mfma_f64(self._h, _dptr(a), _dptr(b), _dptr(out)))
+        return out.reshape(64, 4)

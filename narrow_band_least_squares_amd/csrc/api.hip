@@ -1,0 +1,433 @@
+// C ABI of libnbls_hip.so (see include/nbls.h): handle, HBM buffers, plan, launch order.
+#include "nbls_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_err;   // error of a failed nbls_create
+
+int fail(nbls_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else { std::lock_guard<std::mutex> l(g_err_mu); g_err = msg; }
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, e_ == hipErrorOutOfMemory ? NBLS_ERR_NOMEM : NBLS_ERR_HIP,          \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+template <typename T>
+int ensure(nbls_handle* h, T** p, size_t* cap, size_t need_bytes) {
+    if (*p && *cap >= need_bytes) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    if (need_bytes == 0) need_bytes = 8;
+    hipError_t e = hipMalloc((void**)p, need_bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(h, NBLS_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(need_bytes) + "): " + hipGetErrorString(e));
+    }
+    *cap = need_bytes;
+    return 0;
+}
+
+template <typename T>
+int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(h, hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    if (n) HIPCHK(h, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Zero-input one-chunk transition matrix M = A^C of the DF2T cascade (state order
+// [s1_0, s2_0, s1_1, s2_1, ...]), in long double.
+void chunk_transition(const double* sos, int S, int C, double* M) {
+    const int D = 2 * S;
+    std::vector<long double> A(D * D, 0.0L), R(D * D, 0.0L), Tm(D * D);
+    for (int col = 0; col < D; ++col) {
+        std::vector<long double> st(D, 0.0L);
+        st[col] = 1.0L;
+        long double v = 0.0L;
+        for (int s = 0; s < S; ++s) {
+            const long double b0 = sos[s * 6 + 0], b1 = sos[s * 6 + 1], b2 = sos[s * 6 + 2];
+            const long double a1 = sos[s * 6 + 4], a2 = sos[s * 6 + 5];
+            const long double y = b0 * v + st[2 * s];
+            const long double n1 = (b1 * v - a1 * y) + st[2 * s + 1];
+            const long double n2 = b2 * v - a2 * y;
+            st[2 * s] = n1;
+            st[2 * s + 1] = n2;
+            v = y;
+        }
+        for (int r = 0; r < D; ++r) A[r * D + col] = st[r];
+    }
+    for (int i = 0; i < D; ++i) R[i * D + i] = 1.0L;
+    int e = C;
+    std::vector<long double> B = A;
+    while (e > 0) {
+        if (e & 1) {
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    long double acc = 0.0L;
+                    for (int k = 0; k < D; ++k) acc += R[i * D + k] * B[k * D + j];
+                    Tm[i * D + j] = acc;
+                }
+            R = Tm;
+        }
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                long double acc = 0.0L;
+                for (int k = 0; k < D; ++k) acc += B[i * D + k] * B[k * D + j];
+                Tm[i * D + j] = acc;
+            }
+        B = Tm;
+        e >>= 1;
+    }
+    for (int i = 0; i < D * D; ++i) M[i] = (double)R[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbls_version(void) { return 100; }
+
+const char* nbls_last_error(const nbls_handle* h) {
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> l(g_err_mu);
+    return g_err.c_str();
+}
+
+int nbls_create(int device_id, nbls_handle** out) {
+    if (!out) return fail(nullptr, NBLS_ERR_ARG, "nbls_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NBLS_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, NBLS_ERR_ARG, "nbls_create: device_id out of range");
+    nbls_handle* h = new nbls_handle();
+    h->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess) {
+        delete h;
+        return fail(nullptr, NBLS_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
+    *out = h;
+    return NBLS_OK;
+}
+
+void nbls_destroy(nbls_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
+                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
+                    h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
+                    h->d_starts, h->d_rew, h->d_xs};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!trace || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t pad = (npts + 63) / 64 * 64;
+    if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->d_trace, (size_t)nchans * pad * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(h->d_trace, 0, (size_t)nchans * pad * sizeof(double), h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_trace, pad * sizeof(double), trace, npts * sizeof(double),
+                               npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->nchans = nchans;
+    h->npts = npts;
+    h->npts_pad = pad;
+    h->fs = fs;
+    h->planned = false;
+    return NBLS_OK;
+}
+
+int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx, const double* xpinv,
+                      int32_t npairs) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!xij || !pair_idx || !xpinv) return fail(h, NBLS_ERR_ARG, "nbls_set_geometry: NULL pointer");
+    if (npairs < 3) return fail(h, NBLS_ERR_GEOMETRY, "need at least 3 array elements (3 pairs)");
+    if (npairs > NBLS_MAX_PAIRS) return fail(h, NBLS_ERR_UNSUPPORTED, "more than 512 pairs (32 elements) not supported");
+    // rank check of the co-array (2 unknowns)
+    double sxx = 0, sxy = 0, syy = 0;
+    for (int k = 0; k < npairs; ++k) { sxx += xij[2*k]*xij[2*k]; sxy += xij[2*k]*xij[2*k+1]; syy += xij[2*k+1]*xij[2*k+1]; }
+    const double det = sxx * syy - sxy * sxy;
+    if (!(det > 1e-12 * (sxx + syy) * (sxx + syy)))
+        return fail(h, NBLS_ERR_GEOMETRY, "co-array is rank deficient (collinear array)");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = alloc_copy(h, &h->d_xij, xij, (size_t)npairs * 2))) return rc;
+    if ((rc = alloc_copy(h, &h->d_pair, pair_idx, (size_t)npairs * 2))) return rc;
+    if ((rc = alloc_copy(h, &h->d_xpinv, xpinv, (size_t)npairs * 2))) return rc;
+    h->h_xij.assign(xij, xij + 2 * npairs);
+    h->npairs = npairs;
+    h->planned = false;
+    return NBLS_OK;
+}
+
+int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections, int32_t zero_phase,
+              const double* taper_left, const double* taper_right, int32_t taper_len,
+              const int32_t* winlen, const int32_t* wininc, int32_t vector_len,
+              const nbls_lts_params* lts, int32_t xcorr_impl) {
+    if (!h) return NBLS_ERR_ARG;
+    h->planned = false;
+    if (!h->d_trace) return fail(h, NBLS_ERR_STATE, "nbls_plan: no trace set");
+    if (nbands < 1 || (!sos && nsections != 0) || !winlen || !wininc || vector_len < 1)
+        return fail(h, NBLS_ERR_ARG, "nbls_plan: bad argument");
+    if (nsections < 0 || nsections > NBLS_MAX_SECTIONS)
+        return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: 0..8 second-order sections supported");
+    if (taper_len < 0 || 2 * (int64_t)taper_len > h->npts || (taper_len > 0 && (!taper_left || !taper_right)))
+        return fail(h, NBLS_ERR_ARG, "nbls_plan: bad taper");
+    // geometry is optional for a filter-only plan (filter_data()); execute checks it
+    const int P = h->d_xij ? h->npairs : 1;
+    if (h->d_xij && (int64_t)h->nchans * (h->nchans - 1) / 2 != P)
+        return fail(h, NBLS_ERR_ARG, "nbls_plan: geometry pair count does not match the trace channel count");
+    if (lts) {
+        if (!h->d_xij) return fail(h, NBLS_ERR_STATE, "nbls_plan: LTS needs the geometry");
+        if (h->nchans < 4) return fail(h, NBLS_ERR_GEOMETRY, "LTS needs at least 4 array elements");
+        if (lts->nstarts < 1 || lts->nstarts > NBLS_MAX_STARTS || !lts->starts || !lts->rew_table)
+            return fail(h, NBLS_ERR_ARG, "nbls_plan: bad LTS starts");
+        if (lts->h < 2 || lts->h > P) return fail(h, NBLS_ERR_ARG, "nbls_plan: LTS h out of range");
+        if (lts->ncand < 1 || lts->ncand > NBLS_MAX_CAND) return fail(h, NBLS_ERR_ARG, "nbls_plan: ncand out of range");
+        for (int i = 0; i < lts->nstarts * 4; ++i)
+            if (lts->starts[i] >= P) return fail(h, NBLS_ERR_ARG, "nbls_plan: start index out of range");
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+
+    h->W.assign(winlen, winlen + nbands);
+    h->inc.assign(wininc, wininc + nbands);
+    h->nwin.resize(nbands);
+    h->unit_off.resize(nbands + 1);
+    int64_t U = 0;
+    int maxW = 0;
+    for (int b = 0; b < nbands; ++b) {
+        const int W = winlen[b], inc = wininc[b];
+        if (W < 2 || inc < 1 || (int64_t)W * 2 * sizeof(double) > 60 * 1024)
+            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2..3840 samples");
+        // len(arange(0, npts - W, inc))
+        const int64_t span = h->npts - W;
+        const int64_t n = span > 0 ? (span + inc - 1) / inc : 0;
+        if (n > vector_len) return fail(h, NBLS_ERR_ARG, "nbls_plan: vector_len smaller than a band's window count");
+        h->nwin[b] = (int32_t)n;
+        h->unit_off[b] = (int32_t)U;
+        U += n;
+        if (W > maxW) maxW = W;
+    }
+    h->unit_off[nbands] = (int32_t)U;
+    if (U > 0x7fffffffLL / (P > 0 ? P : 1)) return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: too many (unit, pair) items for one launch");
+    h->nunits = U;
+    h->maxW = maxW;
+    h->nbands = nbands;
+    h->nsections = nsections;
+    h->zero_phase = zero_phase ? 1 : 0;
+    h->taper_len = taper_len;
+    h->vector_len = vector_len;
+    h->xcorr_impl = xcorr_impl;
+    h->nchunks = (h->npts + NBLS_FILTER_CHUNK - 1) / NBLS_FILTER_CHUNK;
+
+    int rc;
+    const int D = 2 * nsections;
+    std::vector<double> M((size_t)nbands * D * D);
+    for (int b = 0; b < nbands; ++b)
+        chunk_transition(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, &M[(size_t)b * D * D]);
+    if ((rc = alloc_copy(h, &h->d_sos, sos, (size_t)nbands * nsections * 6))) return rc;
+    if (nsections == 0 && nbands != 1)
+        return fail(h, NBLS_ERR_ARG, "nbls_plan: an unfiltered plan has exactly one band");
+    if ((rc = alloc_copy(h, &h->d_M, M.data(), M.size()))) return rc;
+    if ((rc = alloc_copy(h, &h->d_tl, taper_left, (size_t)taper_len))) return rc;
+    if ((rc = alloc_copy(h, &h->d_tr, taper_right, (size_t)taper_len))) return rc;
+    if ((rc = alloc_copy(h, &h->d_W, h->W.data(), (size_t)nbands))) return rc;
+    if ((rc = alloc_copy(h, &h->d_inc, h->inc.data(), (size_t)nbands))) return rc;
+    if ((rc = alloc_copy(h, &h->d_nwin, h->nwin.data(), (size_t)nbands))) return rc;
+    if ((rc = alloc_copy(h, &h->d_unit_off, h->unit_off.data(), (size_t)nbands + 1))) return rc;
+    std::vector<int32_t> ub((size_t)U);
+    for (int b = 0; b < nbands; ++b)
+        for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) ub[(size_t)u] = b;
+    if ((rc = alloc_copy(h, &h->d_unit_band, ub.data(), (size_t)U))) return rc;
+
+    const size_t nseries = (size_t)nbands * h->nchans;
+    if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;
+    if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
+    // results: one arena sized for [B][VL] grids
+    const size_t cells = (size_t)nbands * vector_len;
+    const size_t need = cells * sizeof(double);
+    if (need > h->cap_res) {
+        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts};
+        for (void* p : olds) if (p) (void)hipFree(p);
+        h->d_lag = nullptr; h->d_cmax = nullptr; h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = h->d_z = nullptr; h->d_wts = nullptr;
+        h->cap_res = 0;
+    }
+    if (!h->d_vel || h->cap_units < cells * P) {
+        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts};
+        for (void* p : olds) if (p) (void)hipFree(p);
+        HIPCHK(h, hipMalloc((void**)&h->d_lag, cells * P * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->d_cmax, cells * P * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_vel, need));
+        HIPCHK(h, hipMalloc((void**)&h->d_baz, need));
+        HIPCHK(h, hipMalloc((void**)&h->d_mdccm, need));
+        HIPCHK(h, hipMalloc((void**)&h->d_sig, need));
+        HIPCHK(h, hipMalloc((void**)&h->d_z, 2 * need));
+        HIPCHK(h, hipMalloc((void**)&h->d_wts, cells * P));
+        h->cap_res = need;
+        h->cap_units = cells * P;
+    }
+
+    h->lts = lts != nullptr;
+    if (lts) {
+        h->ltsp = *lts;
+        h->ltsp.starts = nullptr;
+        h->ltsp.rew_table = nullptr;
+        if ((rc = alloc_copy(h, &h->d_starts, lts->starts, (size_t)lts->nstarts * 4))) return rc;
+        if ((rc = alloc_copy(h, &h->d_rew, lts->rew_table, (size_t)P + 1))) return rc;
+        std::vector<double> xs((size_t)P * 2);
+        for (int k = 0; k < P; ++k) {
+            xs[2 * k] = h->h_xij[2 * k] / lts->xij_mad[0];
+            xs[2 * k + 1] = h->h_xij[2 * k + 1] / lts->xij_mad[1];
+        }
+        if ((rc = alloc_copy(h, &h->d_xs, xs.data(), xs.size()))) return rc;
+    }
+    h->planned = true;
+    return NBLS_OK;
+}
+
+int nbls_execute(nbls_handle* h) { return nbls_execute_stages(h, 7); }
+
+int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_execute: no plan");
+    if ((stage_mask & 6) && !h->d_xij) return fail(h, NBLS_ERR_STATE, "nbls_execute: no geometry set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t cells = (size_t)h->nbands * h->vector_len;
+    const int P = h->d_xij ? h->npairs : 1;
+    // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272)
+    HIPCHK(h, hipMemsetAsync(h->d_vel, 0, cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_baz, 0, cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_mdccm, 0, cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sig, 0, cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_z, 0, 2 * cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_lag, 0, cells * P * sizeof(int32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_cmax, 0, cells * P * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_wts, 0, cells * P, h->stream));
+    if (h->prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
+    if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if (stage_mask & 2) HIPCHK(h, nbls_launch_xcorr(h));
+    if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if (stage_mask & 4) HIPCHK(h, nbls_launch_solve(h));
+    if (h->prof) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_valid = true; }
+    return NBLS_OK;
+}
+
+int nbls_sync(nbls_handle* h) {
+    if (!h) return NBLS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->prof && h->ev_valid) {
+        float f = 0, x = 0, s = 0, t = 0;
+        HIPCHK(h, hipEventElapsedTime(&f, h->ev[0], h->ev[1]));
+        HIPCHK(h, hipEventElapsedTime(&x, h->ev[1], h->ev[2]));
+        HIPCHK(h, hipEventElapsedTime(&s, h->ev[2], h->ev[3]));
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev[0], h->ev[3]));
+        h->tim.filter_ms = f; h->tim.xcorr_ms = x; h->tim.solve_ms = s; h->tim.total_ms = t;
+        h->ev_valid = false;
+    }
+    return NBLS_OK;
+}
+
+int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* sigma_tau, int32_t* nwin,
+               int32_t* lag, double* cmax, uint8_t* weights, double* z) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_fetch: no plan");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t cells = (size_t)h->nbands * h->vector_len;
+    if (vel) HIPCHK(h, hipMemcpy(vel, h->d_vel, cells * sizeof(double), hipMemcpyDeviceToHost));
+    if (baz) HIPCHK(h, hipMemcpy(baz, h->d_baz, cells * sizeof(double), hipMemcpyDeviceToHost));
+    if (mdccm) HIPCHK(h, hipMemcpy(mdccm, h->d_mdccm, cells * sizeof(double), hipMemcpyDeviceToHost));
+    if (sigma_tau) HIPCHK(h, hipMemcpy(sigma_tau, h->d_sig, cells * sizeof(double), hipMemcpyDeviceToHost));
+    if (nwin) memcpy(nwin, h->nwin.data(), h->nbands * sizeof(int32_t));
+    if (lag) HIPCHK(h, hipMemcpy(lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cmax) HIPCHK(h, hipMemcpy(cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost));
+    if (weights) HIPCHK(h, hipMemcpy(weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost));
+    if (z) HIPCHK(h, hipMemcpy(z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost));
+    return NBLS_OK;
+}
+
+int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out) {
+    if (!h || !out) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_fetch_filtered: no plan");
+    if (band < 0 || band >= h->nbands) return fail(h, NBLS_ERR_ARG, "nbls_fetch_filtered: band out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy2D(out, h->npts * sizeof(double),
+                          h->d_filt + (size_t)band * h->nchans * h->npts_pad, h->npts_pad * sizeof(double),
+                          h->npts * sizeof(double), h->nchans, hipMemcpyDeviceToHost));
+    return NBLS_OK;
+}
+
+int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid) {
+    if (!h || !ptrs) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_device_results: no plan");
+    ptrs[0] = h->d_vel; ptrs[1] = h->d_baz; ptrs[2] = h->d_mdccm; ptrs[3] = h->d_sig; ptrs[4] = h->d_nwin;
+    if (bytes_per_grid) *bytes_per_grid = (int64_t)h->nbands * h->vector_len * (int64_t)sizeof(double);
+    return NBLS_OK;
+}
+
+int nbls_set_profiling(nbls_handle* h, int32_t on) {
+    if (!h) return NBLS_ERR_ARG;
+    h->prof = on != 0;
+    return NBLS_OK;
+}
+
+int nbls_get_timings(nbls_handle* h, nbls_timings* out) {
+    if (!h || !out) return NBLS_ERR_ARG;
+    *out = h->tim;
+    return NBLS_OK;
+}
+
+int nbls_run(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections, int32_t zero_phase,
+             const double* taper_left, const double* taper_right, int32_t taper_len, const int32_t* winlen,
+             const int32_t* wininc, int32_t vector_len, const nbls_lts_params* lts, int32_t xcorr_impl,
+             double* vel, double* baz, double* mdccm, double* sigma_tau, int32_t* nwin, int32_t* lag,
+             double* cmax, uint8_t* weights, double* z) {
+    int rc = nbls_plan(h, nbands, sos, nsections, zero_phase, taper_left, taper_right, taper_len, winlen,
+                       wininc, vector_len, lts, xcorr_impl);
+    if (rc) return rc;
+    if ((rc = nbls_execute(h))) return rc;
+    if ((rc = nbls_sync(h))) return rc;
+    return nbls_fetch(h, vel, baz, mdccm, sigma_tau, nwin, lag, cmax, weights, z);
+}
+
+int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double* out) {
+    if (!h || !a || !b || !out) return NBLS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void**)&da, 64 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&db, 64 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&dout, 256 * sizeof(double)));
+    HIPCHK(h, hipMemcpy(da, a, 64 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(db, b, 64 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, nbls_launch_probe_mfma(h, da, db, dout));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, dout, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return NBLS_OK;
+}
+
+}  // extern "C"

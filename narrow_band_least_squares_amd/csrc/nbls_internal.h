@@ -1,0 +1,83 @@
+// Internal declarations shared by the translation units of libnbls_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/nbls.h"
+
+#define NBLS_MAX_SECTIONS 8
+#define NBLS_FILTER_CHUNK 512      // samples per scan chunk (one lane each)
+#define NBLS_FILTER_TILE 32        // samples per LDS tile row
+#define NBLS_MAX_PAIRS 512
+#define NBLS_MAX_STARTS 1024
+#define NBLS_MAX_CAND 16
+
+struct nbls_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- trace (HBM resident) ----
+    double* d_trace = nullptr;     // [nchans][npts_pad]
+    int nchans = 0;
+    int64_t npts = 0, npts_pad = 0;
+    double fs = 0.0;
+
+    // ---- geometry ----
+    int npairs = 0;
+    double* d_xij = nullptr;       // [P][2]
+    int32_t* d_pair = nullptr;     // [P][2]
+    double* d_xpinv = nullptr;     // [2][P]
+    std::vector<double> h_xij;
+
+    // ---- plan ----
+    bool planned = false;
+    int nbands = 0, nsections = 0, zero_phase = 0, taper_len = 0, vector_len = 0, xcorr_impl = 0;
+    std::vector<int32_t> W, inc, nwin, unit_off;
+    int64_t nunits = 0;
+    int maxW = 0;
+    int64_t nchunks = 0;
+    double* d_sos = nullptr;       // [B][S][6]
+    double* d_M = nullptr;         // [B][D][D] chunk transition (D = 2S)
+    double* d_tl = nullptr;        // [taper_len]
+    double* d_tr = nullptr;        // [taper_len]
+    int32_t* d_W = nullptr;        // [B]
+    int32_t* d_inc = nullptr;      // [B]
+    int32_t* d_nwin = nullptr;     // [B]
+    int32_t* d_unit_off = nullptr; // [B+1]
+    int32_t* d_unit_band = nullptr;// [U]
+
+    // ---- work + results ----
+    double* d_filt = nullptr;      // [B][N][npts_pad]
+    double* d_cstate = nullptr;    // [B*N][nchunks][D]
+    int32_t* d_lag = nullptr;      // [B][VL][P]
+    double* d_cmax = nullptr;      // [B][VL][P]
+    double* d_vel = nullptr;       // [B][VL]
+    double* d_baz = nullptr;
+    double* d_mdccm = nullptr;
+    double* d_sig = nullptr;
+    double* d_z = nullptr;         // [B][VL][2]
+    uint8_t* d_wts = nullptr;      // [B][VL][P]
+    size_t cap_filt = 0, cap_cstate = 0, cap_res = 0, cap_units = 0, cap_bands = 0;
+
+    // ---- LTS ----
+    bool lts = false;
+    nbls_lts_params ltsp{};
+    int32_t* d_starts = nullptr;   // [S][4]
+    double* d_rew = nullptr;       // [P+1]
+    double* d_xs = nullptr;        // [P][2] standardised co-array
+    size_t cap_starts = 0;
+
+    // ---- profiling ----
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    nbls_timings tim{};
+};
+
+// Kernel launchers (each returns hipError_t of the launch).
+hipError_t nbls_launch_filter(nbls_handle* h);
+hipError_t nbls_launch_xcorr(nbls_handle* h);
+hipError_t nbls_launch_solve(nbls_handle* h);
+hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);

@@ -1,0 +1,564 @@
+// MdCCM + slowness solve (ordinary least squares or FAST-LTS with reweighting) for every
+// (band, window) unit of the plan.
+//
+// Replaces, inside lts_array.ltsva (narrow_band_least_squares.py:91,183; source absent,
+// algorithm per SURVEY.md §3.3 / §8 rows a8-a12):
+//   mdccm   = nanmedian_k(cmax_k)
+//   OLS     : z = pinv(X) tau; sigma_tau = sqrt(tau.(tau - X z)/(P-2))
+//   LTS     : y = tau / (1.4826 med|tau|), X = xij / xij_mad;
+//             every elemental start -> exact fit -> <= csteps C-steps (h smallest |r|,
+//             refit, stop when the objective repeats) -> ncand best distinct -> refine to
+//             convergence -> best -> de-standardise -> raw scale -> weights -> WLS refit
+//             -> reweighted scale -> final weights -> z, sigma_tau
+//   vel = 1/||z||, baz = (atan2(z0, z1) deg - 360) mod 360
+//
+// One FAST-LTS start per lane; the 2x2 normal equations are solved per lane (no MFMA: 2x2
+// Gramians); the per-window winner is found by a rank count in LDS.
+//
+// Arithmetic-order contract with oracle/nbls_oracle.py (this file is built with
+// -ffp-contract=off): normal equations accumulated over k = 0..P-1 ascending, Cramer's
+// rule, r_k = (y_k - x_k0 z0) - x_k1 z1, h-subset by stable rank of |r_k|, objective summed
+// over the subset in ascending k.  With identical lags the LTS decisions are then identical.
+#include "nbls_internal.h"
+
+namespace {
+
+struct SArgs {
+    const int32_t* lag;
+    const double* cmax;
+    int npairs;
+    int vector_len;
+    const int32_t* unit_off;
+    const int32_t* unit_band;
+    double fs;
+    const double* xij;     // [P][2]
+    const double* xpinv;   // [2][P]
+    double* vel;
+    double* baz;
+    double* mdccm;
+    double* sig;
+    double* z;
+    uint8_t* wts;
+    // LTS
+    const double* xs;      // [P][2]
+    const int32_t* starts; // [S][4]
+    int nstarts;
+    int h;
+    int csteps, csteps2, ncand;
+    double xmad0, xmad1;
+    double raw_factor;
+    const double* rew;     // [P+1]
+    double quantile;
+    double zero_scale;
+    int use_absr;
+};
+
+__device__ inline double dnan() { return __builtin_nan(""); }
+
+__device__ inline void vel_baz(double z0, double z1, double* vel, double* baz) {
+    *vel = 1.0 / sqrt(z0 * z0 + z1 * z1);
+    const double x = atan2(z0, z1) * 180.0 / 3.141592653589793 - 360.0;
+    double m = fmod(x, 360.0);
+    if (m != 0.0) { if (m < 0.0) m += 360.0; } else m = 0.0;
+    *baz = m;
+}
+
+// nanmedian of v[0..P) read from global memory by ONE thread (rank counting, no storage).
+__device__ double nanmedian_serial(const double* v, int P) {
+    int m = 0;
+    for (int k = 0; k < P; ++k) m += (v[k] == v[k]);
+    if (m == 0) return dnan();
+    const int lo = (m - 1) / 2, hi = m / 2;
+    double vlo = 0.0, vhi = 0.0;
+    for (int k = 0; k < P; ++k) {
+        const double vk = v[k];
+        if (!(vk == vk)) continue;
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const double vj = v[j];
+            rank += (vj < vk) || (vj == vk && j < k);
+        }
+        if (rank == lo) vlo = vk;
+        if (rank == hi) vhi = vk;
+    }
+    return lo == hi ? vlo : (vlo + vhi) * 0.5;
+}
+
+// ------------------------------------------------------------------------------------
+// OLS: one lane per unit.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void solve_ols_kernel(SArgs a, int nunits) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nunits) return;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int P = a.npairs;
+    const int64_t o = (int64_t)band * a.vector_len + w;
+    const int32_t* lag = a.lag + o * P;
+    double z0 = 0.0, z1 = 0.0;
+    for (int k = 0; k < P; ++k) {
+        const double t = (double)lag[k] / a.fs;
+        z0 = z0 + a.xpinv[k] * t;
+        z1 = z1 + a.xpinv[P + k] * t;
+    }
+    double acc = 0.0;
+    for (int k = 0; k < P; ++k) {
+        const double t = (double)lag[k] / a.fs;
+        const double r = t - (a.xij[2 * k] * z0 + a.xij[2 * k + 1] * z1);
+        acc = acc + t * r;
+        a.wts[o * P + k] = 1;
+    }
+    double vel, baz;
+    vel_baz(z0, z1, &vel, &baz);
+    a.vel[o] = vel;
+    a.baz[o] = baz;
+    a.sig[o] = sqrt(acc / (double)(P - 2));
+    a.z[2 * o] = z0;
+    a.z[2 * o + 1] = z1;
+    a.mdccm[o] = nanmedian_serial(a.cmax + o * P, P);
+}
+
+// ------------------------------------------------------------------------------------
+// FAST-LTS: one workgroup (256 lanes) per unit, one elemental start per lane per round.
+// ------------------------------------------------------------------------------------
+constexpr int LT = 256;
+
+struct Sel {
+    double T;    // h-th smallest |r|
+    int m;       // number of |r| == T members to take (in index order)
+    double obj;  // sum of r^2 over the subset, ascending k
+    bool ok;
+};
+
+__device__ inline double resid(const double* y, const double* X0, const double* X1, int k,
+                               double z0, double z1) {
+    return (y[k] - X0[k] * z0) - X1[k] * z1;
+}
+
+template <bool ABSR>
+__device__ Sel select_h(const double* y, const double* X0, const double* X1, int P, int h,
+                        double z0, double z1, double* absr, int tid) {
+    Sel s;
+    s.T = dnan();
+    s.m = 0;
+    s.obj = dnan();
+    s.ok = false;
+    if (ABSR) {
+        for (int k = 0; k < P; ++k) absr[k * LT + tid] = fabs(resid(y, X0, X1, k, z0, z1));
+    }
+    int cl = 0;
+    for (int k = 0; k < P; ++k) {
+        const double ak = ABSR ? absr[k * LT + tid] : fabs(resid(y, X0, X1, k, z0, z1));
+        int less = 0, eq = 0;
+        for (int j = 0; j < P; ++j) {
+            const double aj = ABSR ? absr[j * LT + tid] : fabs(resid(y, X0, X1, j, z0, z1));
+            less += (aj < ak);
+            eq += (aj == ak);
+        }
+        if (less <= h - 1 && h - 1 < less + eq) {
+            s.T = ak;
+            cl = less;
+            s.ok = true;
+        }
+    }
+    if (!s.ok) return s;
+    s.m = h - cl;
+    double obj = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < P; ++k) {
+        const double r = resid(y, X0, X1, k, z0, z1);
+        const double ak = fabs(r);
+        bool in = ak < s.T;
+        if (ak == s.T && cnt < s.m) { in = true; ++cnt; }
+        if (in) obj = obj + r * r;
+    }
+    s.obj = obj;
+    return s;
+}
+
+// LS fit on the subset defined by (zold, T, m): normal equations, ascending k, Cramer.
+__device__ inline void fit_subset(const double* y, const double* X0, const double* X1, int P,
+                                  double zo0, double zo1, double T, int m, double* z0, double* z1) {
+    double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < P; ++k) {
+        const double ak = fabs(resid(y, X0, X1, k, zo0, zo1));
+        bool in = ak < T;
+        if (ak == T && cnt < m) { in = true; ++cnt; }
+        if (in) {
+            const double x0 = X0[k], x1 = X1[k], yk = y[k];
+            sxx = sxx + x0 * x0;
+            sxy = sxy + x0 * x1;
+            syy = syy + x1 * x1;
+            bx = bx + x0 * yk;
+            by = by + x1 * yk;
+        }
+    }
+    const double det = sxx * syy - sxy * sxy;
+    *z0 = (bx * syy - by * sxy) / det;
+    *z1 = (by * sxx - bx * sxy) / det;
+}
+
+// LS fit on an explicit 0/1 mask (uint8 in LDS).
+__device__ inline void fit_mask(const double* y, const double* X0, const double* X1, int P,
+                                const uint8_t* mask, double* z0, double* z1) {
+    double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
+    for (int k = 0; k < P; ++k) {
+        if (mask[k]) {
+            const double x0 = X0[k], x1 = X1[k], yk = y[k];
+            sxx = sxx + x0 * x0;
+            sxy = sxy + x0 * x1;
+            syy = syy + x1 * x1;
+            bx = bx + x0 * yk;
+            by = by + x1 * yk;
+        }
+    }
+    const double det = sxx * syy - sxy * sxy;
+    *z0 = (bx * syy - by * sxy) / det;
+    *z1 = (by * sxx - bx * sxy) / det;
+}
+
+// Block-cooperative: sorted (ascending, NaN skipped) copy of v[0..P) into out; returns count.
+__device__ int block_sort_small(const double* v, int P, double* out, int tid, int* cnt_sh) {
+    if (tid == 0) *cnt_sh = 0;
+    __syncthreads();
+    for (int k = tid; k < P; k += LT) {
+        const double vk = v[k];
+        if (vk == vk) {
+            int rank = 0;
+            for (int j = 0; j < P; ++j) {
+                const double vj = v[j];
+                rank += (vj < vk) || (vj == vk && j < k);
+            }
+            out[rank] = vk;
+            atomicAdd(cnt_sh, 1);
+        }
+    }
+    __syncthreads();
+    return *cnt_sh;
+}
+
+template <bool ABSR>
+__global__ __launch_bounds__(LT) void solve_lts_kernel(SArgs a, int nunits) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x;
+    const int u = blockIdx.x;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int P = a.npairs;
+    const int S = a.nstarts;
+    const int h = a.h;
+    const int64_t o = (int64_t)band * a.vector_len + w;
+
+    // ---- LDS carve-up ----
+    double* tauv = sm;            // [P]
+    double* y = tauv + P;         // [P]
+    double* X0 = y + P;           // [P] standardised
+    double* X1 = X0 + P;
+    double* x0 = X1 + P;          // [P] original km
+    double* x1 = x0 + P;
+    double* tmp = x1 + P;         // [P] scratch (|tau|, cmax, residuals)
+    double* srt = tmp + P;        // [P] sorted scratch
+    double* objS = srt + P;       // [S]
+    double* z0S = objS + S;       // [S]
+    double* z1S = z0S + S;        // [S]
+    double* cres = z1S + S;       // [NBLS_MAX_CAND][3]
+    int* ord = (int*)(cres + 3 * NBLS_MAX_CAND);   // [S]
+    int* rnk = ord + S;           // [P]
+    int* cand = rnk + P;          // [NBLS_MAX_CAND]
+    int* misc = cand + NBLS_MAX_CAND;              // [4]
+    uint8_t* wsh = (uint8_t*)(misc + 4);           // [P]
+    // absr (optional) behind, 8-byte aligned
+    size_t off_bytes = (size_t)((uint8_t*)(wsh + P) - (uint8_t*)sm);
+    off_bytes = (off_bytes + 7) & ~(size_t)7;
+    double* absr = ABSR ? (double*)((uint8_t*)sm + off_bytes) : nullptr;
+
+    for (int k = tid; k < P; k += LT) {
+        const double t = (double)a.lag[o * P + k] / a.fs;
+        tauv[k] = t;
+        tmp[k] = fabs(t);
+        X0[k] = a.xs[2 * k];
+        X1[k] = a.xs[2 * k + 1];
+        x0[k] = a.xij[2 * k];
+        x1[k] = a.xij[2 * k + 1];
+        wsh[k] = 1;
+    }
+    __syncthreads();
+    // tmad = 1.4826 * median |tau|
+    int m = block_sort_small(tmp, P, srt, tid, misc);
+    const double med = (m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5;
+    const double tmad = 1.4826 * med;
+    __syncthreads();
+    // MdCCM
+    for (int k = tid; k < P; k += LT) tmp[k] = a.cmax[o * P + k];
+    __syncthreads();
+    m = block_sort_small(tmp, P, srt, tid, misc);
+    if (tid == 0) {
+        a.mdccm[o] = m == 0 ? dnan()
+                            : ((m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5);
+    }
+    __syncthreads();
+
+    if (tmad == 0.0) {   // "data spike" [R]: not processed
+        if (tid == 0) {
+            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
+            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+        }
+        for (int k = tid; k < P; k += LT) a.wts[o * P + k] = 1;
+        return;
+    }
+    for (int k = tid; k < P; k += LT) y[k] = tauv[k] / tmad;
+    __syncthreads();
+
+    // ---- elemental starts, one per lane ----
+    for (int s = tid; s < ((S + LT - 1) / LT) * LT; s += LT) {
+        double obj = dnan(), z0 = dnan(), z1 = dnan();
+        if (s < S) {
+            const int i0 = a.starts[4 * s], i1 = a.starts[4 * s + 1];
+            const int i2 = a.starts[4 * s + 2], i3 = a.starts[4 * s + 3];
+            double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
+            for (int k = 0; k < P; ++k) {
+                if (k == i0 || k == i1 || k == i2 || k == i3) {
+                    const double c0 = X0[k], c1 = X1[k], yk = y[k];
+                    sxx = sxx + c0 * c0;
+                    sxy = sxy + c0 * c1;
+                    syy = syy + c1 * c1;
+                    bx = bx + c0 * yk;
+                    by = by + c1 * yk;
+                }
+            }
+            const double det = sxx * syy - sxy * sxy;
+            z0 = (bx * syy - by * sxy) / det;
+            z1 = (by * sxx - bx * sxy) / det;
+            Sel sel = select_h<ABSR>(y, X0, X1, P, h, z0, z1, absr, tid);
+            bool active = sel.ok;
+            double prev = 0.0;
+            obj = active ? __builtin_inf() : dnan();
+            for (int kk = 0; kk < a.csteps; ++kk) {
+                if (!active) break;
+                double n0, n1;
+                fit_subset(y, X0, X1, P, z0, z1, sel.T, sel.m, &n0, &n1);
+                sel = select_h<ABSR>(y, X0, X1, P, h, n0, n1, absr, tid);
+                z0 = n0;
+                z1 = n1;
+                if (!sel.ok) { obj = dnan(); active = false; break; }
+                obj = sel.obj;
+                if (kk >= 1 && obj == prev) break;
+                prev = obj;
+            }
+        }
+        if (s < S) { objS[s] = obj; z0S[s] = z0; z1S[s] = z1; }
+    }
+    __syncthreads();
+
+    // ---- rank the starts by (objective, start index); NaN/inf last ----
+    for (int s = tid; s < S; s += LT) {
+        const double os = objS[s];
+        const bool fs_ = (os == os) && os < __builtin_inf();
+        int rank = 0;
+        for (int t = 0; t < S; ++t) {
+            const double ot = objS[t];
+            const bool ft = (ot == ot) && ot < __builtin_inf();
+            bool before;
+            if (ft && fs_) before = (ot < os) || (ot == os && t < s);
+            else if (ft && !fs_) before = true;
+            else if (!ft && fs_) before = false;
+            else before = t < s;
+            rank += before;
+        }
+        ord[rank] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nc = 0;
+        for (int r = 0; r < S && nc < a.ncand; ++r) {
+            const int s = ord[r];
+            const double os = objS[s];
+            if (!((os == os) && os < __builtin_inf())) break;
+            bool dup = false;
+            for (int c = 0; c < nc; ++c) {
+                const int cs = cand[c];
+                if (objS[cs] == os && z0S[cs] == z0S[s] && z1S[cs] == z1S[s]) { dup = true; break; }
+            }
+            if (!dup) cand[nc++] = s;
+        }
+        misc[1] = nc;
+    }
+    __syncthreads();
+    const int nc = misc[1];
+    // ---- refine the candidates to convergence, one per lane ----
+    if (tid < nc) {
+        double z0 = z0S[cand[tid]], z1 = z1S[cand[tid]];
+        Sel sel = select_h<ABSR>(y, X0, X1, P, h, z0, z1, absr, tid);
+        double pobj = 0.0, cobj = __builtin_inf();
+        if (!sel.ok) cobj = dnan();
+        else {
+            for (int kk = 0; kk < a.csteps2; ++kk) {
+                double n0, n1;
+                fit_subset(y, X0, X1, P, z0, z1, sel.T, sel.m, &n0, &n1);
+                sel = select_h<ABSR>(y, X0, X1, P, h, n0, n1, absr, tid);
+                z0 = n0;
+                z1 = n1;
+                if (!sel.ok) { cobj = dnan(); break; }
+                cobj = sel.obj;
+                if (kk >= 1 && cobj == pobj) break;
+                pobj = cobj;
+            }
+        }
+        cres[3 * tid] = cobj;
+        cres[3 * tid + 1] = z0;
+        cres[3 * tid + 2] = z1;
+    }
+    __syncthreads();
+    // ---- best candidate -> de-standardise -> residuals in original units ----
+    double zr0 = dnan(), zr1 = dnan();
+    {
+        double best = __builtin_inf();
+        for (int c = 0; c < nc; ++c) {
+            if (cres[3 * c] < best) { best = cres[3 * c]; zr0 = cres[3 * c + 1]; zr1 = cres[3 * c + 2]; }
+        }
+        zr0 = zr0 * tmad / a.xmad0;
+        zr1 = zr1 * tmad / a.xmad1;
+    }
+    const bool finite_z = (zr0 - zr0 == 0.0) && (zr1 - zr1 == 0.0);
+    if (!finite_z) {
+        if (tid == 0) {
+            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
+            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+        }
+        for (int k = tid; k < P; k += LT) a.wts[o * P + k] = 1;
+        return;
+    }
+    // stable rank of |r_k| (parallel over k)
+    for (int k = tid; k < P; k += LT) tmp[k] = fabs(resid(tauv, x0, x1, k, zr0, zr1));
+    __syncthreads();
+    for (int k = tid; k < P; k += LT) {
+        const double ak = tmp[k];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const double aj = tmp[j];
+            rank += (aj < ak) || (aj == ak && j < k);
+        }
+        rnk[k] = rank;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double ssq = 0.0;
+        for (int k = 0; k < P; ++k) {
+            if (rnk[k] < h) {
+                const double r = resid(tauv, x0, x1, k, zr0, zr1);
+                ssq = ssq + r * r;
+            }
+        }
+        const double s0 = sqrt(ssq / (double)h) * a.raw_factor;
+        double zf0 = zr0, zf1 = zr1;
+        if (fabs(s0) < a.zero_scale) {
+            for (int k = 0; k < P; ++k) wsh[k] = fabs(resid(tauv, x0, x1, k, zr0, zr1)) < a.zero_scale;
+        } else {
+            int nw = 0;
+            for (int k = 0; k < P; ++k) {
+                const double r = resid(tauv, x0, x1, k, zr0, zr1);
+                const uint8_t wk = fabs(r / s0) <= a.quantile;
+                wsh[k] = wk;
+                nw += wk;
+            }
+            fit_mask(tauv, x0, x1, P, wsh, &zf0, &zf1);
+            double ssw = 0.0;
+            for (int k = 0; k < P; ++k) {
+                if (wsh[k]) {
+                    const double r = resid(tauv, x0, x1, k, zf0, zf1);
+                    ssw = ssw + r * r;
+                }
+            }
+            const double scale = nw > 1 ? sqrt(ssw / (double)(nw - 1)) * a.rew[nw] : 0.0;
+            if (scale > 0.0) {
+                for (int k = 0; k < P; ++k) {
+                    const double r = resid(tauv, x0, x1, k, zf0, zf1);
+                    wsh[k] = fabs(r / scale) <= a.quantile;
+                }
+            }
+        }
+        int nw = 0;
+        double acc = 0.0;
+        for (int k = 0; k < P; ++k) {
+            if (wsh[k]) {
+                ++nw;
+                acc = acc + tauv[k] * resid(tauv, x0, x1, k, zf0, zf1);
+            }
+        }
+        double vel, baz;
+        vel_baz(zf0, zf1, &vel, &baz);
+        a.vel[o] = vel;
+        a.baz[o] = baz;
+        a.sig[o] = nw > 2 ? sqrt(acc / (double)(nw - 2)) : dnan();
+        a.z[2 * o] = zf0;
+        a.z[2 * o + 1] = zf1;
+    }
+    __syncthreads();
+    for (int k = tid; k < P; k += LT) a.wts[o * P + k] = wsh[k];
+}
+
+size_t lts_lds_bytes(int P, int S, bool absr) {
+    size_t b = (size_t)(8 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
+    b += (size_t)(S + P + NBLS_MAX_CAND + 4) * sizeof(int);
+    b += (size_t)P;
+    b = (b + 7) & ~(size_t)7;
+    if (absr) b += (size_t)P * LT * sizeof(double);
+    return b;
+}
+
+}  // namespace
+
+hipError_t nbls_launch_solve(nbls_handle* h) {
+    if (h->nunits == 0) return hipSuccess;
+    SArgs a{};
+    a.lag = h->d_lag;
+    a.cmax = h->d_cmax;
+    a.npairs = h->npairs;
+    a.vector_len = h->vector_len;
+    a.unit_off = h->d_unit_off;
+    a.unit_band = h->d_unit_band;
+    a.fs = h->fs;
+    a.xij = h->d_xij;
+    a.xpinv = h->d_xpinv;
+    a.vel = h->d_vel;
+    a.baz = h->d_baz;
+    a.mdccm = h->d_mdccm;
+    a.sig = h->d_sig;
+    a.z = h->d_z;
+    a.wts = h->d_wts;
+    const int nunits = (int)h->nunits;
+    if (!h->lts) {
+        hipLaunchKernelGGL(solve_ols_kernel, dim3((nunits + 255) / 256), dim3(256), 0, h->stream, a, nunits);
+        return hipGetLastError();
+    }
+    a.xs = h->d_xs;
+    a.starts = h->d_starts;
+    a.nstarts = h->ltsp.nstarts;
+    a.h = h->ltsp.h;
+    a.csteps = h->ltsp.csteps;
+    a.csteps2 = h->ltsp.csteps2;
+    a.ncand = h->ltsp.ncand;
+    a.xmad0 = h->ltsp.xij_mad[0];
+    a.xmad1 = h->ltsp.xij_mad[1];
+    a.raw_factor = h->ltsp.raw_factor;
+    a.rew = h->d_rew;
+    a.quantile = h->ltsp.quantile;
+    a.zero_scale = h->ltsp.zero_scale;
+    // cache |r_k| per lane in LDS when a workgroup's slab fits in half a CU's LDS
+    const bool absr = lts_lds_bytes(h->npairs, a.nstarts, true) <= 80 * 1024;
+    a.use_absr = absr;
+    const size_t shm = lts_lds_bytes(h->npairs, a.nstarts, absr);
+    if (shm > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e;
+    if (absr) {
+        e = hipFuncSetAttribute((const void*)solve_lts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((solve_lts_kernel<true>), dim3(nunits), dim3(LT), shm, h->stream, a, nunits);
+    } else {
+        e = hipFuncSetAttribute((const void*)solve_lts_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((solve_lts_kernel<false>), dim3(nunits), dim3(LT), shm, h->stream, a, nunits);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,139 @@
+"""Host driver of the HIP path: turns a stream + band list into one batched device pass
+(filter -> xcorr/lag pick -> MdCCM + OLS|LTS for every band x window) and unpacks the result
+grids.  Used by ``ltsva``, ``filter_data``, ``narrow_band_least_squares*`` and ``bench.py``.
+"""
+import os
+
+import numpy as np
+
+from . import planner
+from ._hip import Handle
+from .stream import start_datenum
+
+_handles = {}
+
+
+def default_device():
+    """NBLS_DEVICE, else LOCAL_RANK (one process per GPU under torch.distributed.run), else 0."""
+    for key in ('NBLS_DEVICE', 'LOCAL_RANK'):
+        v = os.environ.get(key)
+        if v is not None and v != '':
+            return int(v)
+    return 0
+
+
+def get_handle(device=None):
+    """Per-(process, device) handle, created lazily so that a fork before first use is safe."""
+    dev = default_device() if device is None else int(device)
+    key = (os.getpid(), dev)
+    h = _handles.get(key)
+    if h is None:
+        h = Handle(dev)
+        _handles[key] = h
+    return h
+
+
+def stream_to_array(st):
+    """-> (data (N, npts) float64 C-contiguous, fs, start date number)."""
+    nchans = len(st)
+    if nchans == 0:
+        raise ValueError('empty stream')
+    npts = len(st[0].data)
+    fs = float(st[0].stats.sampling_rate)
+    data = np.empty((nchans, npts), dtype=np.float64)
+    for i, tr in enumerate(st):
+        if len(tr.data) != npts:
+            raise ValueError('All traces must have the same number of samples.')
+        data[i] = tr.data
+    return data, fs, start_datenum(getattr(st[0].stats, 'starttime', 0.0))
+
+
+def check_elements(nchans, alpha):
+    if nchans < 3:
+        raise RuntimeError('At least 3 array elements are needed for the least squares estimate.')
+    if alpha < 1.0 and nchans < 4:
+        raise RuntimeError('At least 4 array elements are needed for least trimmed squares.')
+    if not (0.5 <= alpha <= 1.0):
+        raise ValueError('ALPHA must be in [0.5, 1.0].')
+
+
+def window_times(t0_datenum, fs, W, inc, nwin):
+    """t[w] = tvec[w*inc + W//2], tvec = start + (arange(npts)/fs)/86400 (matplotlib dates)."""
+    idx = np.arange(nwin) * inc + int(W / 2)
+    return t0_datenum + (idx / fs) / 86400.0
+
+
+class BandBatch:
+    """Results of one device pass over ``nbands`` bands (arrays are (nbands, vector_len))."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
+            filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
+            want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
+            upload=True):
+    """Run the hot path for a list of bands on one GPU.
+
+    data (N, npts) raw traces; band_edges [(fmin, fmax), ...]; winlens [seconds per band].
+    prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band."""
+    nchans, npts = data.shape
+    check_elements(nchans, alpha)
+    nb = len(band_edges)
+    h = handle if handle is not None else get_handle(device)
+    if upload:
+        h.set_trace(data, fs)
+        xij, pair_idx, xpinv = planner.co_array(rij)
+        h.set_geometry(xij, pair_idx, xpinv)
+    else:
+        xij, pair_idx, xpinv = planner.co_array(rij)
+    W = np.empty(nb, dtype=np.int32)
+    inc = np.empty(nb, dtype=np.int32)
+    nwin = np.empty(nb, dtype=np.int64)
+    for b in range(nb):
+        W[b], inc[b], nwin[b] = planner.window_plan(npts, fs, winlens[b], winover)
+    if vector_len is None:
+        vector_len = max(1, int(nwin.max()))
+    if nwin.max() > vector_len:
+        raise ValueError('could not broadcast %d windows into result rows of length %d '
+                         '(vector_len too small for this band)' % (int(nwin.max()), vector_len))
+    sos_ret = []
+    if prefiltered:
+        if nb != 1:
+            raise ValueError('a pre-filtered pass has exactly one band')
+        sos, zero_phase, tl, tr = None, False, None, None
+    else:
+        applied = []
+        zero_phase = None
+        for (fmin, fmax) in band_edges:
+            sa, zp, sr = planner.design_bandpass(filter_type, fmin, fmax, filter_order, filter_ripple, fs)
+            applied.append(sa)
+            sos_ret.append(sr)
+            zero_phase = zp
+        sos = planner.pad_sections(applied)
+        tl, tr = planner.taper_ramps(npts)
+    lts = planner.lts_plan(xij, alpha) if alpha < 1.0 else None
+    h.plan(sos, zero_phase, tl, tr, W, inc, vector_len, lts=lts, xcorr_impl=xcorr_impl)
+    h.execute()
+    h.sync()
+    out = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_weights=lts is not None, want_z=want_z)
+    t = np.zeros((nb, vector_len))
+    for b in range(nb):
+        t[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
+    return BandBatch(vel=out['vel'], baz=out['baz'], mdccm=out['mdccm'], sigma_tau=out['sigma_tau'],
+                     nwin=out['nwin'].astype(int), t=t, weights=out['weights'], lag=out['lag'],
+                     cmax=out['cmax'], z=out['z'], sos=sos_ret, W=W, inc=inc, pair_idx=pair_idx,
+                     xij=xij, nchans=nchans, alpha=alpha, handle=h)
+
+
+def stdict_from_weights(weights_row, nwin, t_row, pair_idx, nchans):
+    """lts_array's dropped-element dictionary for one band: key ``str(t)`` -> 1-based element
+    numbers of both members of every zero-weight pair; ``'size'`` -> number of elements."""
+    stdict = {}
+    for w in range(nwin):
+        drop = np.where(weights_row[w] == 0)[0]
+        if len(drop) > 0:
+            stdict[str(t_row[w])] = np.concatenate((pair_idx[drop, 0] + 1, pair_idx[drop, 1] + 1))
+    stdict['size'] = nchans
+    return stdict

@@ -1,0 +1,45 @@
+"""GPU ``ltsva``: drop-in for ``from lts_array import ltsva`` (reference call sites
+narrow_band_least_squares.py:91,183 and example.py:109; the lts_array source itself is an
+empty git submodule in the reference checkout, so the algorithm follows the published one as
+summarised in SURVEY.md §3.3).
+"""
+import numpy as np
+
+from . import engine
+from .helpers import get_rij
+
+
+def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
+          plot_array_coordinates=False, rij=None):
+    """Window the (already filtered) stream, pick pairwise cross-correlation lags and solve for
+    the slowness vector by OLS (``alpha == 1.0``) or FAST-LTS (``0.5 <= alpha < 1``).
+
+    Returns ``(vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz)``:
+    trace velocity km/s, back-azimuth degrees in [0, 360), window-centre times as matplotlib
+    date numbers, median cross-correlation maximum, dropped-element dictionary (``{}`` for
+    OLS), sigma_tau seconds, and the two confidence-interval vectors (NaN: not yet computed on
+    this path).  ``rij`` (2, N) km overrides the lat/lon geometry."""
+    data, fs, t0 = engine.stream_to_array(st)
+    nchans = data.shape[0]
+    engine.check_elements(nchans, alpha)
+    if rij is None:
+        rij = get_rij(lat_list, lon_list, nchans)
+    if alpha == 1.0:
+        print('ALPHA is 1.0. Performing an ordinary least squares fit, NOT least trimmed squares.')
+    if plot_array_coordinates:
+        import warnings
+        warnings.warn('plot_array_coordinates is not supported on the HIP path; ignored.')
+    res = engine.process(data, fs, t0, rij, [(None, None)], [window_length], window_overlap, alpha,
+                         prefiltered=True)
+    n = int(res.nwin[0])
+    vel = res.vel[0, :n].copy()
+    baz = res.baz[0, :n].copy()
+    t = res.t[0, :n].copy()
+    mdccm = res.mdccm[0, :n].copy()
+    sigma_tau = res.sigma_tau[0, :n].copy()
+    if alpha == 1.0:
+        stdict = {}
+    else:
+        stdict = engine.stdict_from_weights(res.weights[0], n, t, res.pair_idx, nchans)
+    nanv = np.full(n, np.nan)
+    return vel, baz, t, mdccm, stdict, sigma_tau, nanv, nanv.copy()

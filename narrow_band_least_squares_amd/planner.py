@@ -1,0 +1,198 @@
+"""Host-side planning for the HIP path: filter design, taper ramps, window plan, co-array,
+and the FAST-LTS constants / start list.  Everything here is small NumPy/SciPy work done once
+per call; the per-sample and per-window arithmetic runs in ``csrc/*.hip``.
+
+Reference sources restated (file:line relative to the reference checkout; [R] = recalled
+public algorithm of a dependency whose source is not in the checkout):
+
+* filter design ............ helpers.py:126-130; obspy ``bandpass`` [R]
+* taper .................... helpers.py:139; obspy ``Trace.taper`` [R]
+* windows .................. lts_array ``DataBin`` [R]
+* co-array, h, starts ...... lts_array ``LsBeam`` / ``LTSEstimator`` [R]
+* scale factors ............ R ``robustbase::ltsReg`` (``LTScnp2``, ``LTScnp2.rew``) [R]
+"""
+import math
+
+import numpy as np
+from scipy import signal
+from scipy.stats import norm
+
+# ---- FAST-LTS constants [R]; one place to correct them against the real lts_array ----
+LTS_N_SAMPLES = 500
+LTS_CSTEPS = 4
+LTS_CSTEPS2 = 100
+LTS_CANDIDATES = 10
+LTS_DIM = 2
+LTS_QUANTILE = float(norm.ppf(0.9875))
+LTS_ZERO_SCALE = 1e-7
+MAD_CONST = 1.4826
+TAPER_FRACTION = 0.01          # helpers.py:139
+
+
+def design_bandpass(filter_type, fmin, fmax, order, ripple, fs):
+    """-> (sos applied to the data, zero_phase flag, sos returned to the caller)."""
+    if filter_type == 'butter':
+        fe = 0.5 * fs
+        low, high = fmin / fe, fmax / fe
+        if high - 1.0 > -1e-6:
+            import warnings
+            warnings.warn('Selected high corner frequency (%s) of bandpass is at or above Nyquist (%s). '
+                          'Applying a high-pass instead.' % (fmax, fe))
+            z, p, k = signal.iirfilter(order, low, btype='highpass', ftype='butter', output='zpk')
+        else:
+            if low > 1:
+                raise ValueError('Selected low corner frequency is above Nyquist.')
+            z, p, k = signal.iirfilter(order, [low, high], btype='band', ftype='butter', output='zpk')
+        sos_apply = signal.zpk2sos(z, p, k)
+        sos_ret = signal.iirfilter(order, [fmin, fmax], btype='band', ftype='butter', fs=fs, output='sos')
+        return sos_apply, True, sos_ret
+    if filter_type == 'cheby1':
+        sos = signal.iirfilter(order, [fmin, fmax], rp=ripple, btype='band', analog=False,
+                               ftype='cheby1', fs=fs, output='sos')
+        return sos, False, sos
+    raise ValueError('unknown FILTER_TYPE %r (expected "butter" or "cheby1")' % (filter_type,))
+
+
+def pad_sections(sos_list):
+    """Stack per-band SOS arrays to (B, Smax, 6), padding with identity sections."""
+    smax = max(s.shape[0] for s in sos_list)
+    out = np.zeros((len(sos_list), smax, 6))
+    out[:, :, 0] = 1.0
+    out[:, :, 3] = 1.0
+    for b, s in enumerate(sos_list):
+        out[b, :s.shape[0], :] = s
+    return out
+
+
+def taper_ramps(npts, max_percentage=TAPER_FRACTION):
+    """Left and right ramps of obspy's Hann taper (ones in between are implicit)."""
+    wlen = min(int(max_percentage * npts), int(npts / 2))
+    if wlen == 0:
+        return np.zeros(0), np.zeros(0)
+    sides = signal.windows.hann(2 * wlen if 2 * wlen == npts else 2 * wlen + 1)
+    return np.ascontiguousarray(sides[:wlen]), np.ascontiguousarray(sides[len(sides) - wlen:])
+
+
+def window_plan(npts, fs, window_length, window_overlap):
+    """(W, inc, number of windows): W = int(winlen*fs), inc = int(round((1-ov)*W)),
+    windows start at arange(0, npts - W, inc)."""
+    W = int(window_length * fs)
+    inc = int(np.round((1 - window_overlap) * W))
+    if W < 2 or inc < 1:
+        raise ValueError('window length / overlap give an empty window or zero hop')
+    nwin = len(np.arange(0, npts - W, inc))
+    return W, inc, nwin
+
+
+def pair_table(nchans):
+    return np.array([(i, j) for i in range(nchans - 1) for j in range(i + 1, nchans)], dtype=np.int32)
+
+
+def co_array(rij):
+    """rij (2, N) km -> xij (P, 2) = r_i - r_j, pair table (P, 2), pinv(xij) (2, P)."""
+    rij = np.asarray(rij, dtype=np.float64)
+    idx = pair_table(rij.shape[1])
+    xij = np.ascontiguousarray((rij[:, idx[:, 0]] - rij[:, idx[:, 1]]).T)
+    if np.linalg.matrix_rank(xij) < LTS_DIM:
+        raise RuntimeError('Co-array is ill posed for the least squares problem. Check array coordinates.')
+    return xij, idx, np.ascontiguousarray(np.linalg.pinv(xij))
+
+
+def lts_h(P, alpha, p=LTS_DIM):
+    n2 = (P + p + 1) // 2
+    return int(math.floor(2 * n2 - P + 2 * (P - n2) * alpha))
+
+
+def uniran_subsets(P, n_samples=LTS_N_SAMPLES, p=LTS_DIM):
+    """robustbase LCG (seed*5761+999 mod 65536), seed 0, carried across subsets."""
+    seed = 0
+    out = np.empty((n_samples, p), dtype=np.int64)
+    for s in range(n_samples):
+        chosen = []
+        for _ in range(p):
+            while True:
+                seed = (seed * 5761 + 999) % 65536
+                num = int(math.floor(seed / 65536.0 * P))
+                if num not in chosen:
+                    break
+            chosen.append(num)
+        out[s] = chosen
+    return out
+
+
+def lts_starts(xs):
+    """Elemental starts on the standardised co-array: every 2-subset if there are at most
+    LTS_N_SAMPLES of them, else LTS_N_SAMPLES LCG-random ones; rank-deficient subsets are
+    extended until they have rank 2.  (S, 4) int32, -1 padded."""
+    P = xs.shape[0]
+    if P * (P - 1) // 2 <= LTS_N_SAMPLES:
+        subs = [(i, j) for i in range(P - 1) for j in range(i + 1, P)]
+    else:
+        subs = [tuple(r) for r in uniran_subsets(P)]
+    out = -np.ones((len(subs), 4), dtype=np.int32)
+    scale = np.max(np.abs(xs)) ** 2
+    for s, sub in enumerate(subs):
+        sub = list(sub)
+        nxt = 0
+        while True:
+            g = xs[sub].T @ xs[sub]
+            det = g[0, 0] * g[1, 1] - g[0, 1] * g[1, 0]
+            if det > 1e-12 * scale * scale or len(sub) >= 4:
+                break
+            while nxt in sub:
+                nxt += 1
+            if nxt >= P:
+                break
+            sub.append(nxt)
+        out[s, :len(sub)] = sub
+    return out
+
+
+def _consfactor(m, n):
+    if m >= n or m <= 0:
+        return 1.0
+    q = norm.ppf((m + n) / (2.0 * n))
+    return 1.0 / math.sqrt(1.0 - (2.0 * n) / (m / q) * norm.pdf(q))
+
+
+def _cnp2(p, n, alpha, c500, c875):
+    c500 = np.asarray(c500, dtype=float)
+    c875 = np.asarray(c875, dtype=float)
+    y500 = np.log(-c500[0] / p ** c500[1])
+    y875 = np.log(-c875[0] / p ** c875[1])
+    k500 = np.linalg.solve(np.column_stack((np.ones(2), -np.log(c500[2] * p ** 2))), y500)
+    k875 = np.linalg.solve(np.column_stack((np.ones(2), -np.log(c875[2] * p ** 2))), y875)
+    fp500 = 1 - math.exp(k500[0]) / n ** k500[1]
+    fp875 = 1 - math.exp(k875[0]) / n ** k875[1]
+    if alpha <= 0.875:
+        fp = fp500 + (fp875 - fp500) / 0.375 * (alpha - 0.5)
+    else:
+        fp = fp875 + (1 - fp875) / 0.125 * (alpha - 0.875)
+    return 1.0 / fp
+
+
+# robustbase LTScnp2 / LTScnp2.rew coefficient tables, no-intercept, p >= 2 [R]
+_RAW_500 = [[-0.487338281979106, -0.340762058011], [0.405511279418594, 0.37972360544988], [3, 5]]
+_RAW_875 = [[-0.251778730491252, -0.146660023184295], [0.883966931611758, 0.86292940340761], [3, 5]]
+_REW_500 = [[-0.417574780492848, -0.175753709374146], [1.83958876341367, 1.8313809497999], [3, 5]]
+_REW_875 = [[-0.267522855927958, -0.161200683014406], [1.17559984533974, 1.21675019853961], [3, 5]]
+
+
+def lts_plan(xij, alpha):
+    """Everything the LTS kernel needs besides the lags (see ``nbls_lts_params``)."""
+    if not (0.5 <= alpha < 1.0):
+        raise ValueError('LTS needs 0.5 <= ALPHA < 1.0')
+    P = xij.shape[0]
+    h = lts_h(P, alpha)
+    xij_mad = MAD_CONST * np.median(np.abs(xij), axis=0)
+    if not np.all(xij_mad > 0):
+        raise RuntimeError('Co-array MAD is zero along an axis; cannot standardise for LTS.')
+    starts = lts_starts(xij / xij_mad)
+    raw = _consfactor(h, P) * _cnp2(LTS_DIM, P, alpha, _RAW_500, _RAW_875)
+    rew = np.ones(P + 1)
+    cor = _cnp2(LTS_DIM, P, alpha, _REW_500, _REW_875)
+    for nw in range(1, P):
+        rew[nw] = _consfactor(nw, P) * cor
+    return dict(alpha=alpha, h=h, starts=starts, csteps=LTS_CSTEPS, csteps2=LTS_CSTEPS2,
+                ncand=LTS_CANDIDATES, xij_mad=xij_mad, raw_factor=raw, rew_table=rew,
+                quantile=LTS_QUANTILE, zero_scale=LTS_ZERO_SCALE)

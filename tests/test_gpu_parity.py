@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path (through the ctypes C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances: lags / weights / dropped elements exact; filtered samples 1e-11 of
+the trace scale; MdCCM 1e-12 relative; vel / baz / sigma_tau 1e-9 relative (north_star asks 1e-6).
+"""
+import numpy as np
+import pytest
+
+from narrow_band_least_squares_amd import (engine, synthetic, filter_data, ltsva, narrow_band_least_squares,
+                                           narrow_band_loop, get_rij)
+from narrow_band_least_squares_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _cfg(name, scale):
+    return synthetic.build_config(name, scale=scale)
+
+
+def _ostream(oracle, c):
+    return oracle.make_stream(c['data'], c['fs'], starttime=c['st'][0].stats.starttime)
+
+
+def test_library_loads_and_device_opens():
+    h = engine.get_handle()
+    assert h.lib.nbls_version() >= 100
+
+
+def test_mfma_f64_layout():
+    """A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D[i][j] at lane = j + 16*(i%4), reg = i//4."""
+    rng = np.random.default_rng(1)
+    A = rng.integers(-8, 8, size=(16, 4)).astype(float)
+    B = rng.integers(-8, 8, size=(4, 16)).astype(float)
+    a = np.zeros(64); b = np.zeros(64)
+    for lane in range(64):
+        a[lane] = A[lane & 15, lane >> 4]
+        b[lane] = B[lane >> 4, lane & 15]
+    out = engine.get_handle().probe_mfma_f64(a, b)
+    D = A @ B
+    got = np.zeros((16, 16))
+    for lane in range(64):
+        for reg in range(4):
+            got[(lane >> 4) + 4 * reg, lane & 15] = out[lane, reg]
+    np.testing.assert_array_equal(got, D)
+
+
+@pytest.mark.parametrize('ftype,fmin,fmax', [('butter', 0.5, 2.0), ('cheby1', 0.1, 0.5), ('butter', 0.1, 0.16)])
+def test_filter_data_parity(oracle, ftype, fmin, fmax):
+    c = _cfg('cfg1b', 1.0)
+    stf_o, fs_o, sos_o = oracle.filter_data(_ostream(oracle, c), ftype, fmin, fmax, 2, 0.01)
+    stf, fs, sos = filter_data(c['st'], ftype, fmin, fmax, 2, 0.01)
+    assert fs == fs_o
+    np.testing.assert_array_equal(sos, sos_o)
+    scale = max(np.abs(tr.data).max() for tr in stf_o)
+    for a, b in zip(stf, stf_o):
+        assert len(a.data) == len(b.data)
+        assert np.max(np.abs(a.data - b.data)) <= 1e-11 * scale
+    # the input stream is not modified
+    np.testing.assert_array_equal(c['st'][0].data, c['data'][0])
+
+
+def _compare_ltsva(oracle, c, stf_o, winlen, alpha):
+    out_o, internals = oracle.ltsva(stf_o, None, None, winlen, 0.5, alpha, rij=c['rij'], return_internals=True)
+    data = np.array([tr.data for tr in stf_o])
+    res = engine.process(data, c['fs'], oracle.start_datenum(stf_o[0].stats.starttime), c['rij'],
+                         [(None, None)], [winlen], 0.5, alpha, prefiltered=True, want_lag=True,
+                         want_cmax=True, want_z=True)
+    n = int(res.nwin[0])
+    assert n == len(out_o[0])
+    lag_o = np.rint(internals['tau'].T * c['fs']).astype(int)
+    np.testing.assert_array_equal(res.lag[0, :n], lag_o)
+    np.testing.assert_allclose(res.cmax[0, :n], internals['cmax'].T, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(res.mdccm[0, :n], out_o[3], rtol=1e-12)
+    np.testing.assert_array_equal(res.t[0, :n], out_o[2])
+    np.testing.assert_allclose(res.z[0, :n], internals['z'].T, rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(res.vel[0, :n], out_o[0], rtol=RTOL)
+    np.testing.assert_allclose(res.baz[0, :n], out_o[1], rtol=RTOL)
+    np.testing.assert_allclose(res.sigma_tau[0, :n], out_o[5], rtol=1e-7, atol=1e-12, equal_nan=True)
+    if alpha < 1.0:
+        np.testing.assert_array_equal(res.weights[0, :n], internals['weights'].T)
+    return out_o
+
+
+@pytest.mark.parametrize('alpha', [1.0, 0.75, 0.5])
+def test_ltsva_parity(oracle, alpha):
+    c = _cfg('cfg2', 0.25)
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 2.0, 2, 0.01)
+    out_o = _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
+    # the public entry point, with the drop-in 8-tuple
+    st = synthetic.make_stream(np.array([tr.data for tr in stf_o]), c['fs'], starttime=c['st'][0].stats.starttime)
+    vel, baz, t, mdccm, stdict, sig, cv, cb = ltsva(st, None, None, 30.0, 0.5, alpha, False, rij=c['rij'])
+    np.testing.assert_allclose(vel, out_o[0], rtol=RTOL)
+    np.testing.assert_allclose(baz, out_o[1], rtol=RTOL)
+    np.testing.assert_array_equal(t, out_o[2])
+    assert set(stdict.keys()) == set(out_o[4].keys())
+    for k in stdict:
+        np.testing.assert_array_equal(stdict[k], out_o[4][k])
+    assert len(cv) == len(vel) and len(cb) == len(vel)
+
+
+def test_ltsva_eight_elements_lts(oracle):
+    c = _cfg('cfg3', 0.02)     # 8 elements, 28 pairs, 378 starts
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 1.0, 4.0, 2, 0.01)
+    _compare_ltsva(oracle, c, stf_o, 30.0, 0.5)
+
+
+def _compare_nbls(oracle, c, freq_resp, **kw):
+    w = np.zeros(len(freq_resp)); h = np.zeros(len(freq_resp))
+    args = (c['WINLEN_list'], c['overlap'], c['alpha'], None, None, None, c['NBANDS'], w, h, c['freqlist'],
+            c['band_type'], freq_resp, c['ftype'], c['order'], c['ripple'])
+    a = list(args); a[3] = c['st']
+    got = narrow_band_least_squares(*a, rij=c['rij'])
+    a[3] = _ostream(oracle, c)
+    exp = oracle.narrow_band_least_squares(*a, rij=c['rij'])
+    assert got[6] == exp[6]
+    for i, name in ((0, 'vel'), (1, 'baz'), (2, 'mdccm')):
+        np.testing.assert_allclose(got[i], exp[i], rtol=RTOL, atol=0, err_msg=name)
+    np.testing.assert_array_equal(got[3], exp[3])
+    np.testing.assert_allclose(got[5], exp[5], rtol=1e-7, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(got[7], exp[7], rtol=1e-13)
+    np.testing.assert_allclose(got[8], exp[8], rtol=1e-12, atol=1e-300)
+    if c['alpha'] == 1.0:
+        assert got[4] is None and exp[4] is None
+    else:
+        assert set(got[4].keys()) == set(exp[4].keys())
+        for k in got[4]:
+            np.testing.assert_array_equal(got[4][k], exp[4][k])
+    return got, exp
+
+
+def test_narrow_band_cfg1_ols_butter(oracle):
+    c = _cfg('cfg1', 1.0)
+    _compare_nbls(oracle, c, np.logspace(-2, 1, 200))
+
+
+def test_narrow_band_cfg1b_example_parameters(oracle):
+    """example.py's literal parameters: 8 log bands 0.1-5 Hz, cheby1/2/0.01, adaptive 60->30 s."""
+    c = _cfg('cfg1b', 1.0)
+    got, exp = _compare_nbls(oracle, c, np.logspace(-2, 1, 1000))
+    assert got[6] == [39, 42, 46, 50, 56, 62, 69, 79]
+    assert got[0].shape == (8, 80)
+
+
+def test_narrow_band_cfg2_lts(oracle):
+    c = _cfg('cfg2', 0.2)
+    c['alpha'] = 0.5
+    got, exp = _compare_nbls(oracle, c, np.logspace(-2, 1, 100))
+    assert any(k != 'size' for k in got[4])
+
+
+def test_narrow_band_loop_matches_batched_row(oracle):
+    c = _cfg('cfg1', 0.5)
+    fr = np.logspace(-2, 1, 50)
+    w = np.zeros(50)
+    full = narrow_band_least_squares(c['WINLEN_list'], 0.5, 1.0, c['st'], None, None, c['NBANDS'], w, w,
+                                     c['freqlist'], 'linear', fr, 'butter', 2, 0.01, rij=c['rij'])
+    vl = full[0].shape[1]
+    row = narrow_band_loop(3, c['freqlist'], 'linear', fr, c['st'], 'butter', 2, 0.01, None, None,
+                           c['WINLEN_list'], 0.5, 1.0, vl, rij=c['rij'])
+    np.testing.assert_array_equal(row[0], full[0][3])
+    np.testing.assert_array_equal(row[1], full[1][3])
+    np.testing.assert_array_equal(row[2], full[2][3])
+    np.testing.assert_array_equal(row[6], full[5][3])
+    assert int(row[7]) == full[6][3]
+    assert row[4] is None and row[5] is None
+
+
+def test_zero_channel_nan_semantics(oracle):
+    """An all-zero element: its pairs give 0/0 -> NaN maxima, argmax 0 (lag W-1), nanmedian skips them."""
+    c = _cfg('cfg1', 0.25)
+    data = c['data'].copy()
+    data[2] = 0.0
+    st_o = oracle.make_stream(data, c['fs'], starttime=c['st'][0].stats.starttime)
+    _compare_ltsva(oracle, c, st_o, 30.0, 1.0)
+
+
+def test_errors_match_reference_types():
+    c = _cfg('cfg1', 0.1)
+    with pytest.raises(ValueError):
+        get_rij([1.0, 2.0], [1.0], 2)
+    st2 = synthetic.make_stream(c['data'][:2], c['fs'])
+    with pytest.raises(RuntimeError):
+        ltsva(st2, None, None, 30.0, 0.5, 1.0, rij=c['rij'][:, :2])
+    st3 = synthetic.make_stream(c['data'][:3], c['fs'])
+    with pytest.raises(RuntimeError):
+        ltsva(st3, None, None, 30.0, 0.5, 0.75, rij=c['rij'][:, :3])
+    line = np.vstack((np.arange(4.0), np.zeros(4)))
+    st4 = synthetic.make_stream(c['data'][:4], c['fs'])
+    with pytest.raises(RuntimeError):
+        ltsva(st4, None, None, 30.0, 0.5, 1.0, rij=line)
+
+
+def test_short_trace_gives_no_windows():
+    c = _cfg('cfg1', 0.02)    # 480 samples < 600-sample window
+    vel, baz, t, mdccm, stdict, sig, _, _ = ltsva(c['st'], None, None, 30.0, 0.5, 1.0, rij=c['rij'])
+    assert len(vel) == 0 and len(t) == 0 and stdict == {}
+
+
+def test_full_size_cfg3_properties():
+    """BASELINE configs[2] at full size (69 024 units): size-independent properties — the plane wave
+    is recovered in the signal band, the corrupted element is what LTS drops, two runs are bit
+    identical, and a band subset reproduces the same rows (what band sharding relies on)."""
+    c = _cfg('cfg3', 1.0)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    edges = [(c['freqlist'][i], c['freqlist'][i + 1]) for i in range(c['NBANDS'])]
+    r1 = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], 0.5, 0.5, 'butter', 2, 0.01)
+    assert int(r1.nwin.sum()) == 69024
+    n = int(r1.nwin[24])
+    baz = r1.baz[24, :n]; vel = r1.vel[24, :n]
+    assert abs(np.nanmedian(baz) - 225.0) < 1.5
+    assert abs(np.nanmedian(vel) - 0.34) < 0.01
+    dropped = r1.weights[24, :n] == 0
+    bad_pairs = (r1.pair_idx[:, 0] == 7) | (r1.pair_idx[:, 1] == 7)
+    assert dropped[:, bad_pairs].mean() > 0.9 and dropped[:, ~bad_pairs].mean() < 0.1
+    r2 = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], 0.5, 0.5, 'butter', 2, 0.01)
+    for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'weights'):
+        np.testing.assert_array_equal(getattr(r1, k), getattr(r2, k))
+    sub = [5, 24, 40]
+    r3 = engine.process(data, fs, t0, c['rij'], [edges[i] for i in sub], [c['WINLEN_list'][i] for i in sub],
+                        0.5, 0.5, 'butter', 2, 0.01, vector_len=r1.vel.shape[1])
+    for j, i in enumerate(sub):
+        for k in ('vel', 'baz', 'mdccm', 'weights'):
+            np.testing.assert_array_equal(getattr(r3, k)[j], getattr(r1, k)[i])
