@@ -22,7 +22,6 @@ def install_as_reference_modules():
     """Register this package's modules under the reference's module names, so that a script
     written like the reference's example.py (``from narrow_band_least_squares import ...``,
     ``from helpers import ...``, ``from lts_array import ltsva``) runs on the GPU path unchanged."""
-    from . import narrow_band_least_squares as _nbls, helpers as _helpers, lts_array as _lts
-    _sys.modules['narrow_band_least_squares'] = _nbls
-    _sys.modules['helpers'] = _helpers
-    _sys.modules['lts_array'] = _lts
+    # (the package attribute `narrow_band_least_squares` is the function; fetch the modules by name)
+    for name in ('narrow_band_least_squares', 'helpers', 'lts_array'):
+        _sys.modules[name] = _sys.modules[__name__ + '.' + name]

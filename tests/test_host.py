@@ -1,0 +1,139 @@
+"""CPU tests of the host side: planners against the reference's goldens, the duck-typed stream,
+text I/O, the C ABI's exported symbols, loud failure without a GPU, the LTS plan against the oracle's
+constants, and the N>1 (band-sharded) path under gloo with world_size 2."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import narrow_band_least_squares_amd as pkg
+from narrow_band_least_squares_amd import _hip, dist, planner, synthetic
+from narrow_band_least_squares_amd.stream import Stream, Trace, Stats, start_datenum
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_planners_match_reference_goldens():
+    g = json.load(open(os.path.join(GOLD, 'planners.json')))
+    for kind in ('linear', 'log', 'octave', '2_octave_over', 'onethird_octave', 'octave_linear'):
+        e = g['freqlist_' + kind]
+        fl, nb, fmax = pkg.get_freqlist(e['args'][0], e['args'][1], kind, e['args'][2])
+        assert [float(x) for x in fl] == e['freqlist'], kind
+        assert nb == e['nbands'] and float(fmax) == e['fmax']
+    assert pkg.get_winlenlist('adaptive', 8, 50, 60, 30) == g['winlen_adaptive'] == [60, 55, 51, 47, 42, 38, 34, 30]
+    assert pkg.get_winlenlist('constant', 5, 50, 60, 30) == g['winlen_constant']
+    fl, _, _ = pkg.get_freqlist(0.1, 5.0, 'log', 8)
+    assert fl[0] == 0.10000000000000005            # math.log(0.1, 10) quirk of helpers.py:30
+    rij = pkg.get_rij(g['get_rij']['lat'], g['get_rij']['lon'], 4)
+    np.testing.assert_allclose(rij, np.array(g['get_rij']['rij']), rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        pkg.get_rij([1.0, 2.0], [1.0], 2)
+
+
+def test_make_float_and_txt_roundtrip(tmp_path, capsys):
+    assert pkg.make_float([np.float32(1.5), 2]).dtype == np.float64
+    vel = np.array([[0.3, 0.31, 0.0], [0.4, 0.41, 0.42]])
+    baz = vel * 100
+    md = vel / 2
+    t = np.array([[1.0, 2.0, 0.0], [1.5, 2.5, 3.5]])
+    pkg.write_txtfile(str(tmp_path) + '/', 'res', vel, baz, md, t, [0.5, 1.0, 2.0], [2, 3])
+    capsys.readouterr()
+    head = open(str(tmp_path) + '/res.txt').readline()
+    assert head == 'Fmin \t Fmax \t Time \t Trace_vel \t Backaz \t MdCCM \n'
+    v2, b2, m2, t2, fl, ncl, nb, fmin, fmax = pkg.read_txtfile(str(tmp_path) + '/', 'res')
+    assert nb == 2 and list(ncl) == [2, 3] and list(fl) == [0.5, 1.0, 2.0] and (fmin, fmax) == (0.5, 2.0)
+    np.testing.assert_array_equal(v2[1], vel[1])
+    np.testing.assert_array_equal(v2[0, :2], vel[0, :2])
+
+
+def test_stream_duck_type():
+    st = synthetic.make_stream(np.arange(12.0).reshape(3, 4), 2.0, starttime=100.0)
+    c = st.copy()
+    c[0].data = c[0].data * 2
+    assert st[0].data[1] == 1.0 and c[0].data[1] == 2.0 and len(st) == 3
+    np.testing.assert_array_equal(st[1].times('matplotlib'), 100.0 + (np.arange(4) / 2.0) / 86400.0)
+    assert np.asarray(st[2]).shape == (4,) and st[2].stats.npts == 4
+    assert start_datenum(np.datetime64('1970-01-02T00:00:00')) == 1.0
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'nbls.h')).read()
+    declared = sorted(set(re.findall(r'\b(nbls_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_hip.EXPORTS) == declared
+    assert _hip.load_library().nbls_version() >= 100
+
+
+def test_fails_loudly_without_gpu_or_library(tmp_path):
+    with pytest.raises(ImportError):
+        _hip.load_library(str(tmp_path / 'nope.so'))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_hip.NblsError):
+        _hip.Handle(0)
+    c = synthetic.build_config('cfg1', 0.05)
+    with pytest.raises(_hip.NblsError):
+        pkg.ltsva(c['st'], None, None, 5.0, 0.5, 1.0, rij=c['rij'])
+
+
+def test_package_does_not_import_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, 'narrow_band_least_squares_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(root, f)).read()
+                assert 'nbls_oracle' not in txt.replace('oracle/nbls_oracle.py', ''), f
+
+
+def test_lts_plan_matches_oracle_constants(oracle):
+    rng = np.random.default_rng(1)
+    for n, alpha in ((6, 0.75), (8, 0.5), (16, 0.5)):
+        rij = rng.uniform(-1, 1, size=(2, n))
+        xij, idx, xpinv = planner.co_array(rij)
+        xo, io = oracle.co_array(rij)
+        np.testing.assert_array_equal(xij, xo)
+        assert [tuple(r) for r in idx] == io
+        lp = planner.lts_plan(xij, alpha)
+        h, raw, rew = oracle.lts_scale_tables(xij.shape[0], alpha)
+        assert lp['h'] == h and lp['raw_factor'] == raw
+        np.testing.assert_array_equal(lp['rew_table'], rew)
+        xs = xij / (oracle.MAD_CONST * np.median(np.abs(xij), axis=0))
+        np.testing.assert_array_equal(lp['starts'], oracle.lts_starts(xs))
+        assert lp['quantile'] == oracle.LTS_QUANTILE and lp['csteps'] == oracle.LTS_CSTEPS
+    W, inc, nwin = planner.window_plan(24001, 20.0, 30, 0.5)
+    assert (W, inc, nwin) == (600, 300, 79)
+    with pytest.raises(RuntimeError):
+        planner.co_array(np.vstack((np.arange(4.0), np.zeros(4))))
+    with pytest.raises(ValueError):
+        planner.design_bandpass('bessel', 1, 2, 2, 0.1, 20.0)
+
+
+def test_shard_bands_is_a_balanced_partition():
+    costs = dist.band_costs(864000, 40.0, [60, 55, 51, 47, 42, 38, 34, 30] * 6, 0.5, 28)
+    for world in (1, 2, 4, 8):
+        shards = dist.shard_bands(costs, world)
+        assert sorted(b for s in shards for b in s) == list(range(48))
+        loads = [sum(costs[b] for b in s) for s in shards]
+        assert max(loads) <= 1.2 * (sum(costs) / world)
+    assert dist.shard_bands([1.0, 1.0], 4) == [[0], [1], [], []]
+    assert dist.dist_info()[1] == 1
+
+
+@pytest.mark.parametrize('gold', ['loop_ols_butter_linear', 'loop_lts_butter_octave'])
+def test_band_sharded_path_world_size_2_gloo(gold):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29533',
+           os.path.join(ROOT, 'tests', '_dist_worker.py'), gold]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DIST_OK world=2' in r.stdout
