@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -289,6 +290,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     }
 
     h->lts = lts != nullptr;
+    { const char* e = getenv("NBLS_LTS_IMPL"); h->lts_impl = e ? atoi(e) : 0; }
     if (lts) {
         h->ltsp = *lts;
         h->ltsp.starts = nullptr;

@@ -498,6 +498,352 @@ __global__ __launch_bounds__(LT) void solve_lts_kernel(SArgs a, int nunits) {
     for (int k = tid; k < P; k += LT) a.wts[o * P + k] = wsh[k];
 }
 
+
+// ------------------------------------------------------------------------------------
+// FAST-LTS, register-resident form for P known at compile time (P <= 64).
+// One workgroup per unit, ONE elemental start per lane (blockDim = starts rounded up to a
+// wave multiple, <= 512; more starts -> several rounds).  Each lane keeps its P absolute
+// residuals in registers; the stable rank of every |r_k| is counted with fully unrolled
+// compares (j < k: a_j <= a_k, j > k: a_j < a_k), giving the h-subset as a bit mask.
+// The 2x2 normal equations are accumulated from per-unit product tables in LDS (broadcast
+// reads).  The ncand best DISTINCT starts are peeled off by repeated workgroup arg-min with
+// duplicate knock-out, refined one per lane, and lane 0 finishes (de-standardise, raw scale,
+// weights, WLS refit, reweighting).  Same arithmetic order as the generic kernel / the oracle.
+// ------------------------------------------------------------------------------------
+template <int PT>
+struct RegSel {
+    unsigned long long mask;
+    double obj;
+    bool ok;
+};
+
+template <int PT>
+__device__ inline RegSel<PT> select_reg(const double* y, const double* X0, const double* X1, int h,
+                                        double z0, double z1) {
+    double a[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) a[k] = fabs((y[k] - X0[k] * z0) - X1[k] * z1);
+    RegSel<PT> s;
+    s.mask = 0ull;
+    s.obj = dnan();
+    s.ok = false;
+    double T = 0.0;
+    int kstar = -1;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            if (j < k) rank += (a[j] <= a[k]) ? 1 : 0;
+            else if (j > k) rank += (a[j] < a[k]) ? 1 : 0;
+        }
+        if (rank == h - 1 && a[k] == a[k]) { T = a[k]; kstar = k; }
+    }
+    if (kstar < 0) return s;
+    s.ok = true;
+    double obj = 0.0;
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const bool in = (a[k] < T) || (a[k] == T && k <= kstar);
+        obj = in ? obj + a[k] * a[k] : obj;
+        m |= in ? (1ull << k) : 0ull;
+    }
+    s.mask = m;
+    s.obj = obj;
+    return s;
+}
+
+// Normal equations over the masked pairs from the product tables (ascending k), Cramer.
+template <int PT>
+__device__ inline void fit_reg(const double* txx, const double* txy, const double* tyy, const double* tbx,
+                               const double* tby, unsigned long long mask, double* z0, double* z1) {
+    double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const bool in = (mask >> k) & 1ull;
+        sxx = in ? sxx + txx[k] : sxx;
+        sxy = in ? sxy + txy[k] : sxy;
+        syy = in ? syy + tyy[k] : syy;
+        bx = in ? bx + tbx[k] : bx;
+        by = in ? by + tby[k] : by;
+    }
+    const double det = sxx * syy - sxy * sxy;
+    *z0 = (bx * syy - by * sxy) / det;
+    *z1 = (by * sxx - bx * sxy) / det;
+}
+
+__device__ inline int block_sort_any(const double* v, int P, double* out, int tid, int nthr, int* cnt_sh) {
+    if (tid == 0) *cnt_sh = 0;
+    __syncthreads();
+    for (int k = tid; k < P; k += nthr) {
+        const double vk = v[k];
+        if (vk == vk) {
+            int rank = 0;
+            for (int j = 0; j < P; ++j) {
+                const double vj = v[j];
+                rank += (vj < vk) || (vj == vk && j < k);
+            }
+            out[rank] = vk;
+            atomicAdd(cnt_sh, 1);
+        }
+    }
+    __syncthreads();
+    return *cnt_sh;
+}
+
+template <int PT>
+__global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    const int u = blockIdx.x;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    constexpr int P = PT;
+    const int S = a.nstarts;
+    const int h = a.h;
+    const int64_t o = (int64_t)band * a.vector_len + w;
+
+    double* tauv = sm;            // [P]
+    double* y = tauv + P;
+    double* X0 = y + P;
+    double* X1 = X0 + P;
+    double* x0 = X1 + P;
+    double* x1 = x0 + P;
+    double* txx = x1 + P;         // X0*X0, X0*X1, X1*X1, X0*y, X1*y (standardised)
+    double* txy = txx + P;
+    double* tyy = txy + P;
+    double* tbx = tyy + P;
+    double* tby = tbx + P;
+    double* tmp = tby + P;
+    double* srt = tmp + P;
+    double* objS = srt + P;       // [S]
+    double* z0S = objS + S;
+    double* z1S = z0S + S;
+    double* cres = z1S + S;       // [NBLS_MAX_CAND][3]
+    double* wminv = cres + 3 * NBLS_MAX_CAND;      // [8]
+    int* wmins = (int*)(wminv + 8);                // [8]
+    int* cand = wmins + 8;                         // [NBLS_MAX_CAND]
+    int* misc = cand + NBLS_MAX_CAND;              // [4]
+    uint8_t* alive = (uint8_t*)(misc + 4);         // [S]
+    uint8_t* wsh = alive + S;                      // [P]
+
+    for (int k = tid; k < P; k += nthr) {
+        const double t = (double)a.lag[o * P + k] / a.fs;
+        tauv[k] = t;
+        tmp[k] = fabs(t);
+        X0[k] = a.xs[2 * k];
+        X1[k] = a.xs[2 * k + 1];
+        x0[k] = a.xij[2 * k];
+        x1[k] = a.xij[2 * k + 1];
+        wsh[k] = 1;
+    }
+    __syncthreads();
+    int m = block_sort_any(tmp, P, srt, tid, nthr, misc);
+    const double med = (m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5;
+    const double tmad = 1.4826 * med;
+    __syncthreads();
+    for (int k = tid; k < P; k += nthr) tmp[k] = a.cmax[o * P + k];
+    __syncthreads();
+    m = block_sort_any(tmp, P, srt, tid, nthr, misc);
+    if (tid == 0)
+        a.mdccm[o] = m == 0 ? dnan() : ((m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5);
+    __syncthreads();
+    if (tmad == 0.0) {
+        if (tid == 0) {
+            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
+            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+        }
+        for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = 1;
+        return;
+    }
+    for (int k = tid; k < P; k += nthr) {
+        const double yk = tauv[k] / tmad;
+        const double c0 = X0[k], c1 = X1[k];
+        y[k] = yk;
+        txx[k] = c0 * c0;
+        txy[k] = c0 * c1;
+        tyy[k] = c1 * c1;
+        tbx[k] = c0 * yk;
+        tby[k] = c1 * yk;
+    }
+    __syncthreads();
+
+    // ---- elemental starts ----
+    for (int s = tid; s < ((S + nthr - 1) / nthr) * nthr; s += nthr) {
+        if (s < S) {
+            unsigned long long sm_ = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = a.starts[4 * s + q];
+                if (idx >= 0) sm_ |= 1ull << idx;
+            }
+            double z0, z1, obj;
+            fit_reg<PT>(txx, txy, tyy, tbx, tby, sm_, &z0, &z1);
+            RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
+            bool active = sel.ok;
+            double prev = 0.0;
+            obj = active ? __builtin_inf() : dnan();
+            for (int kk = 0; kk < a.csteps; ++kk) {
+                if (!active) break;
+                double n0, n1;
+                fit_reg<PT>(txx, txy, tyy, tbx, tby, sel.mask, &n0, &n1);
+                sel = select_reg<PT>(y, X0, X1, h, n0, n1);
+                z0 = n0;
+                z1 = n1;
+                if (!sel.ok) { obj = dnan(); active = false; break; }
+                obj = sel.obj;
+                if (kk >= 1 && obj == prev) break;
+                prev = obj;
+            }
+            objS[s] = obj;
+            z0S[s] = z0;
+            z1S[s] = z1;
+            alive[s] = (obj == obj) && obj < __builtin_inf();
+        }
+    }
+    __syncthreads();
+
+    // ---- peel off the ncand best distinct starts: arg-min over (obj, s), knock out duplicates ----
+    int nc = 0;
+    for (int it = 0; it < a.ncand; ++it) {
+        double bv = __builtin_inf();
+        int bs = 0x7fffffff;
+        for (int s = tid; s < S; s += nthr) {
+            if (alive[s]) {
+                const double ov = objS[s];
+                if (ov < bv || (ov == bv && s < bs)) { bv = ov; bs = s; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int os = __shfl_xor(bs, off, 64);
+            if (ov < bv || (ov == bv && os < bs)) { bv = ov; bs = os; }
+        }
+        if (lane == 0) { wminv[wv] = bv; wmins[wv] = bs; }
+        __syncthreads();
+        bv = wminv[0];
+        bs = wmins[0];
+        for (int q = 1; q < nwv; ++q) {
+            const double ov = wminv[q];
+            const int os = wmins[q];
+            if (ov < bv || (ov == bv && os < bs)) { bv = ov; bs = os; }
+        }
+        if (bs == 0x7fffffff) break;      // nothing alive (uniform: every lane read the same words)
+        const double w0 = z0S[bs], w1 = z1S[bs];
+        __syncthreads();                  // everyone has read wmin*/the winner before they change
+        for (int s = tid; s < S; s += nthr)
+            if (alive[s] && objS[s] == bv && z0S[s] == w0 && z1S[s] == w1) alive[s] = 0;
+        if (tid == 0) cand[nc] = bs;
+        ++nc;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- refine, one candidate per lane ----
+    if (tid < nc) {
+        double z0 = z0S[cand[tid]], z1 = z1S[cand[tid]];
+        RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
+        double pobj = 0.0, cobj = __builtin_inf();
+        if (!sel.ok) cobj = dnan();
+        else {
+            for (int kk = 0; kk < a.csteps2; ++kk) {
+                double n0, n1;
+                fit_reg<PT>(txx, txy, tyy, tbx, tby, sel.mask, &n0, &n1);
+                sel = select_reg<PT>(y, X0, X1, h, n0, n1);
+                z0 = n0;
+                z1 = n1;
+                if (!sel.ok) { cobj = dnan(); break; }
+                cobj = sel.obj;
+                if (kk >= 1 && cobj == pobj) break;
+                pobj = cobj;
+            }
+        }
+        cres[3 * tid] = cobj;
+        cres[3 * tid + 1] = z0;
+        cres[3 * tid + 2] = z1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double zr0 = dnan(), zr1 = dnan();
+        double best = __builtin_inf();
+        for (int c = 0; c < nc; ++c)
+            if (cres[3 * c] < best) { best = cres[3 * c]; zr0 = cres[3 * c + 1]; zr1 = cres[3 * c + 2]; }
+        zr0 = zr0 * tmad / a.xmad0;
+        zr1 = zr1 * tmad / a.xmad1;
+        const bool finite_z = (zr0 - zr0 == 0.0) && (zr1 - zr1 == 0.0);
+        if (!finite_z) {
+            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
+            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+        } else {
+            RegSel<PT> sel = select_reg<PT>(tauv, x0, x1, h, zr0, zr1);
+            const double s0 = sqrt(sel.obj / (double)h) * a.raw_factor;
+            double zf0 = zr0, zf1 = zr1;
+            if (fabs(s0) < a.zero_scale) {
+                for (int k = 0; k < P; ++k) wsh[k] = fabs(resid(tauv, x0, x1, k, zr0, zr1)) < a.zero_scale;
+            } else {
+                int nw = 0;
+                for (int k = 0; k < P; ++k) {
+                    const double r = resid(tauv, x0, x1, k, zr0, zr1);
+                    const uint8_t wk = fabs(r / s0) <= a.quantile;
+                    wsh[k] = wk;
+                    nw += wk;
+                }
+                fit_mask(tauv, x0, x1, P, wsh, &zf0, &zf1);
+                double ssw = 0.0;
+                for (int k = 0; k < P; ++k) {
+                    if (wsh[k]) {
+                        const double r = resid(tauv, x0, x1, k, zf0, zf1);
+                        ssw = ssw + r * r;
+                    }
+                }
+                const double scale = nw > 1 ? sqrt(ssw / (double)(nw - 1)) * a.rew[nw] : 0.0;
+                if (scale > 0.0) {
+                    for (int k = 0; k < P; ++k) {
+                        const double r = resid(tauv, x0, x1, k, zf0, zf1);
+                        wsh[k] = fabs(r / scale) <= a.quantile;
+                    }
+                }
+            }
+            int nw = 0;
+            double acc = 0.0;
+            for (int k = 0; k < P; ++k) {
+                if (wsh[k]) {
+                    ++nw;
+                    acc = acc + tauv[k] * resid(tauv, x0, x1, k, zf0, zf1);
+                }
+            }
+            double vel, baz;
+            vel_baz(zf0, zf1, &vel, &baz);
+            a.vel[o] = vel;
+            a.baz[o] = baz;
+            a.sig[o] = nw > 2 ? sqrt(acc / (double)(nw - 2)) : dnan();
+            a.z[2 * o] = zf0;
+            a.z[2 * o + 1] = zf1;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = wsh[k];
+}
+
+size_t lts_fast_lds_bytes(int P, int S) {
+    size_t b = (size_t)(13 * P + 3 * S + 3 * NBLS_MAX_CAND + 8) * sizeof(double);
+    b += (size_t)(8 + NBLS_MAX_CAND + 4) * sizeof(int);
+    b += (size_t)S + P;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int PT>
+hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits) {
+    const int S = a.nstarts;
+    int nthr = ((S + 63) / 64) * 64;
+    if (nthr > 512) nthr = 512;
+    const size_t shm = lts_fast_lds_bytes(PT, S);
+    hipLaunchKernelGGL((solve_lts_fast_kernel<PT>), dim3(nunits), dim3(nthr), shm, h->stream, a, nunits);
+    return hipGetLastError();
+}
+
 size_t lts_lds_bytes(int P, int S, bool absr) {
     size_t b = (size_t)(8 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
     b += (size_t)(S + P + NBLS_MAX_CAND + 4) * sizeof(int);
@@ -545,6 +891,16 @@ hipError_t nbls_launch_solve(nbls_handle* h) {
     a.rew = h->d_rew;
     a.quantile = h->ltsp.quantile;
     a.zero_scale = h->ltsp.zero_scale;
+    if (h->lts_impl != 1) {
+        switch (h->npairs) {     // register-resident kernel for 4..8 elements (larger P spills registers)
+            case 6: return launch_fast<6>(h, a, nunits);
+            case 10: return launch_fast<10>(h, a, nunits);
+            case 15: return launch_fast<15>(h, a, nunits);
+            case 21: return launch_fast<21>(h, a, nunits);
+            case 28: return launch_fast<28>(h, a, nunits);
+            default: break;
+        }
+    }
     // cache |r_k| per lane in LDS when a workgroup's slab fits in half a CU's LDS
     const bool absr = lts_lds_bytes(h->npairs, a.nstarts, true) <= 80 * 1024;
     a.use_absr = absr;

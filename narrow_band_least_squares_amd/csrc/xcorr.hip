@@ -29,6 +29,10 @@ struct XArgs {
     int vector_len;
     int32_t* lag;             // [B][VL][P]
     double* cmax;             // [B][VL][P]
+    // f64-MFMA kernel only
+    int S;                    // lag blocks (of 16) per tile = floor(16 / (N-1))
+    int CS;                   // LDS elements per channel buffer, == 2 (mod 32)
+    int PF;                   // zero padding in front of each channel window
 };
 
 __device__ inline bool better(double v1, int k1, double v2, int k2) {
@@ -113,8 +117,125 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// v2: FP64 matrix-core kernel (v_mfma_f64_16x16x4_f64).  One workgroup per unit, one wave per
+// "sliding" channel i.  The whole N-channel window sits in LDS once (zero padded, one buffer per
+// channel).  For wave i the positive-lag correlations against ALL other channels are a
+// Toeplitz product that maps onto 16x16 MFMA tiles with no wasted lanes:
+//
+//     C[r][c] = sum_n'  A[r][n'] * B[n'][c],   A[r][n'] = x_i[n' + r + D0]
+//                                              B[n'][c] = x_j(c)[n' - 16 s(c)]
+//     => C[r][c] = sum_n x_i[n + d] x_j[n],    d = D0 + 16 s(c) + r
+//
+// rows r = 16 consecutive lags, columns c = (partner j, lag block s): (N-1)*S of the 16 columns
+// are live (14/16 for N = 8).  A tile step covers 16*S lags of every partner; its K loop runs
+// only over the n' that can overlap (W - D0), so the triangular lag/overlap structure costs
+// ~16*S/2 wasted samples per lag instead of W/2.  Negative lags of pair (i, j) are the positive
+// lags of wave j against partner i, so every ordered (i, j) is one column family and the total
+// is P * W^2 multiply-adds, as in the direct form.
+//
+// LDS reads per MFMA: two ds_read_b64 (one A, one B value per lane).  A lanes read <= 17
+// consecutive doubles (broadcast + conflict free); B lanes read one double per (column, k):
+// with the channel stride CS == 2 (mod 32) doubles and the 16-sample block shift, the 32
+// addresses of a half-wave fall on 32 distinct bank pairs.
+//
+// Per-lane running (max, first index) over its 4 accumulator rows and all tile steps, then a
+// shuffle reduce over the 4 lanes of a column, then one LDS hand-off to combine the two
+// orderings of each pair.  Ties resolve to the smaller np.correlate index, like np.argmax.
+// ------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;                    // sliding channel of this wave
+    const int N = a.nchans;
+    const int u = blockIdx.x;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int W = a.Wb[band];
+    const int64_t t0 = (int64_t)w * a.incb[band];
+    const int S = a.S, CS = a.CS, PF = a.PF;
+    double* nrm = sm + (size_t)N * CS;          // [N] sum of squares
+    double* cbv = nrm + N;                      // [N][16] best value per (wave, column)
+    int* cbk = (int*)(cbv + N * 16);            // [N][16] its np.correlate index
+
+    {   // stage: wave wv loads channel wv (zero padded) and its sum of squares
+        double* ch = sm + (size_t)wv * CS;
+        const double* src = a.filt + ((int64_t)band * N + wv) * a.npts_pad + t0;
+        double q = 0.0;
+        for (int n = lane; n < CS; n += 64) {
+            const int idx = n - PF;
+            const double v = (idx >= 0 && idx < W) ? src[idx] : 0.0;
+            ch[n] = v;
+            q += v * v;
+        }
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        if (lane == 0) nrm[wv] = q;
+    }
+    __syncthreads();
+
+    const int c = lane & 15, kq = lane >> 4;
+    const int ncol = (N - 1) * S;
+    const bool colvalid = c < ncol;
+    const int jj = colvalid ? c % (N - 1) : 0;
+    const int s = colvalid ? c / (N - 1) : 0;
+    const int j = jj + (jj >= wv ? 1 : 0);      // partner channel of this column
+    const double* pa = sm + (size_t)wv * CS + PF + kq + c;        // + D0 + n'   (row r = lane & 15)
+    const double* pb = sm + (size_t)j * CS + PF + kq - 16 * s;    // + n'
+    double bestv = -__builtin_inf();
+    int bestk = 0x7fffffff;
+    const int step = 16 * S;
+    for (int D0 = 0; D0 < W; D0 += step) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const int klen = W - D0;
+        const double* qa = pa + D0;
+        const double* qb = pb;
+        int n0 = 0;
+        for (; n0 + 28 < klen; n0 += 32) {
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[n0 + 4 * uu], qb[n0 + 4 * uu], acc, 0, 0, 0);
+        }
+        for (; n0 < klen; n0 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[n0], qb[n0], acc, 0, 0, 0);
+        if (colvalid) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int d = D0 + 16 * s + kq + 4 * reg;
+                if (d < W) {
+                    const int kk = (wv < j) ? (W - 1 + d) : (W - 1 - d);
+                    if (better(acc[reg], kk, bestv, bestk)) { bestv = acc[reg]; bestk = kk; }
+                }
+            }
+        }
+    }
+    for (int off = 16; off <= 32; off <<= 1) {
+        const double ov = __shfl_xor(bestv, off, 64);
+        const int ok = __shfl_xor(bestk, off, 64);
+        if (better(ov, ok, bestv, bestk)) { bestv = ov; bestk = ok; }
+    }
+    if (lane < 16) { cbv[wv * 16 + lane] = bestv; cbk[wv * 16 + lane] = bestk; }
+    __syncthreads();
+    if (tid < a.npairs) {
+        const int ci = a.pair[2 * tid], cj = a.pair[2 * tid + 1];     // ci < cj
+        double bv = -__builtin_inf();
+        int bk = 0x7fffffff;
+        for (int ss = 0; ss < S; ++ss) {
+            const int c1 = (cj - 1) + (N - 1) * ss;     // wave ci, partner cj
+            if (better(cbv[ci * 16 + c1], cbk[ci * 16 + c1], bv, bk)) { bv = cbv[ci * 16 + c1]; bk = cbk[ci * 16 + c1]; }
+            const int c2 = ci + (N - 1) * ss;           // wave cj, partner ci
+            if (better(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
+        }
+        const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + tid;
+        a.lag[o] = (W - 1) - bk;
+        a.cmax[o] = bv / sqrt(nrm[ci] * nrm[cj]);
+    }
+}
+
 __global__ void probe_mfma_f64_kernel(const double* a, const double* b, double* out) {
-    typedef double d4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[lane], b[lane], acc, 0, 0, 0);
@@ -141,10 +262,31 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     if (h->nunits == 0) return hipSuccess;
+    h->tim.xcorr_launches = 1;
+    // f64-MFMA kernel: needs one wave per channel (N <= 16) and the N-channel window in LDS
+    const int N = h->nchans;
+    bool mfma_ok = N >= 3 && N <= 16 && h->npairs <= 64 * N;
+    size_t shm_m = 0;
+    if (mfma_ok) {
+        a.S = 16 / (N - 1);
+        a.PF = 16 * (a.S - 1);
+        int cs = a.PF + h->maxW + 32;
+        cs += ((2 - cs) % 32 + 32) % 32;            // CS == 2 (mod 32)
+        a.CS = cs;
+        shm_m = ((size_t)N * cs + N + N * 16) * sizeof(double) + (size_t)N * 16 * sizeof(int);
+        if (shm_m > 160 * 1024) mfma_ok = false;
+    }
+    if (h->xcorr_impl == 2 && !mfma_ok) return hipErrorInvalidValue;
+    if (mfma_ok && h->xcorr_impl != 1) {
+        hipError_t e = hipFuncSetAttribute((const void*)xcorr_mfma_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(xcorr_mfma_kernel, dim3((unsigned)h->nunits), dim3(64 * N), shm_m, h->stream, a);
+        return hipGetLastError();
+    }
     const int64_t nblocks = h->nunits * h->npairs;
     const size_t shm = (size_t)2 * h->maxW * sizeof(double);
     hipLaunchKernelGGL(xcorr_simple_kernel, dim3((unsigned)nblocks), dim3(256), shm, h->stream, a);
-    h->tim.xcorr_launches = 1;
     return hipGetLastError();
 }
 

@@ -166,6 +166,25 @@ def test_narrow_band_loop_matches_batched_row(oracle):
     assert row[4] is None and row[5] is None
 
 
+def test_kernel_variants_agree(monkeypatch):
+    """The f64-MFMA correlator against the plain VALU one (lags identical, maxima to rounding) and the
+    register-resident LTS kernel against the generic one (bit identical)."""
+    c = _cfg('cfg3', 0.03)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    edges = [(0.2, 0.5), (1.0, 3.0), (4.0, 8.0)]
+    kw = dict(want_lag=True, want_cmax=True, want_z=True)
+    r_mfma = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
+    r_valu = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=1, **kw)
+    np.testing.assert_array_equal(r_mfma.lag, r_valu.lag)
+    np.testing.assert_allclose(r_mfma.cmax, r_valu.cmax, rtol=1e-12, atol=1e-15)
+    for k in ('vel', 'baz', 'sigma_tau', 'weights', 'z'):
+        np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_valu, k))
+    monkeypatch.setenv('NBLS_LTS_IMPL', '1')
+    r_gen = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
+    for k in ('vel', 'baz', 'sigma_tau', 'weights', 'z', 'mdccm'):
+        np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_gen, k))
+
+
 def test_zero_channel_nan_semantics(oracle):
     """An all-zero element: its pairs give 0/0 -> NaN maxima, argmax 0 (lag W-1), nanmedian skips them."""
     c = _cfg('cfg1', 0.25)
