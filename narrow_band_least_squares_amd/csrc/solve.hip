@@ -20,6 +20,7 @@
 // rule, r_k = (y_k - x_k0 z0) - x_k1 z1, h-subset by stable rank of |r_k|, objective summed
 // over the subset in ascending k.  With identical lags the LTS decisions are then identical.
 #include "nbls_internal.h"
+#include <utility>
 
 namespace {
 
@@ -517,88 +518,143 @@ struct RegSel {
     bool ok;
 };
 
+// branch-free "v if bit else +0.0" (the compiler turns a ?: around an LDS load into a branch)
+__device__ inline double keep_if(double v, unsigned int bit) {
+    const unsigned long long m = 0ull - (unsigned long long)bit;
+    return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & m));
+}
+
+// stable rank of a[K] among a[0..PT): #{j<K: a_j <= a_K} + #{j>K: a_j < a_K}; compile-time indices
+// only (index_sequence fold), so the array stays in registers.
+template <int PT, int K, int... J>
+__device__ inline int rank_of(const double (&a)[PT], std::integer_sequence<int, J...>) {
+    return (0 + ... + (J < K ? ((a[J] <= a[K]) ? 1 : 0) : (J > K ? ((a[J] < a[K]) ? 1 : 0) : 0)));
+}
+
+template <int PT, int... K>
+__device__ inline void find_threshold(const double (&a)[PT], int h, double& T, int& kstar,
+                                      std::integer_sequence<int, K...>) {
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int r = rank_of<PT, k>(a, std::make_integer_sequence<int, PT>{});
+        const bool hit = (r == h - 1) & (a[k] == a[k]);
+        T = hit ? a[k] : T;
+        kstar = hit ? k : kstar;
+    };
+    (one(std::integral_constant<int, K>{}), ...);
+}
+
+template <int PT, int... K>
+__device__ inline void residuals_reg(double (&a)[PT], const double* y, const double* X0, const double* X1,
+                                     double z0, double z1, std::integer_sequence<int, K...>) {
+    ((a[K] = fabs((y[K] - X0[K] * z0) - X1[K] * z1)), ...);
+}
+
+template <int PT, int... K>
+__device__ inline void subset_reg(const double (&a)[PT], double T, int kstar, unsigned long long& mask,
+                                  double& obj, std::integer_sequence<int, K...>) {
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned int in = ((a[k] < T) | ((a[k] == T) & (k <= kstar))) ? 1u : 0u;
+        obj = obj + keep_if(a[k] * a[k], in);
+        mask |= (unsigned long long)in << k;
+    };
+    (one(std::integral_constant<int, K>{}), ...);
+}
+
 template <int PT>
-__device__ inline RegSel<PT> select_reg(const double* y, const double* X0, const double* X1, int h,
+__device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* X0, const double* X1, int h,
                                         double z0, double z1) {
+    using Seq = std::make_integer_sequence<int, PT>;
     double a[PT];
-#pragma unroll
-    for (int k = 0; k < PT; ++k) a[k] = fabs((y[k] - X0[k] * z0) - X1[k] * z1);
+    // compiler barrier: without it LICM hoists every loop-invariant LDS table read of the C-step
+    // loop into registers (hundreds of VGPRs) and the kernel spills
+    asm volatile("" ::: "memory");
+    residuals_reg<PT>(a, y, X0, X1, z0, z1, Seq{});
     RegSel<PT> s;
     s.mask = 0ull;
     s.obj = dnan();
     s.ok = false;
     double T = 0.0;
     int kstar = -1;
-#pragma unroll
-    for (int k = 0; k < PT; ++k) {
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            if (j < k) rank += (a[j] <= a[k]) ? 1 : 0;
-            else if (j > k) rank += (a[j] < a[k]) ? 1 : 0;
-        }
-        if (rank == h - 1 && a[k] == a[k]) { T = a[k]; kstar = k; }
-    }
+    find_threshold<PT>(a, h, T, kstar, Seq{});
     if (kstar < 0) return s;
     s.ok = true;
     double obj = 0.0;
     unsigned long long m = 0ull;
-#pragma unroll
-    for (int k = 0; k < PT; ++k) {
-        const bool in = (a[k] < T) || (a[k] == T && k <= kstar);
-        obj = in ? obj + a[k] * a[k] : obj;
-        m |= in ? (1ull << k) : 0ull;
-    }
+    subset_reg<PT>(a, T, kstar, m, obj, Seq{});
     s.mask = m;
     s.obj = obj;
     return s;
 }
 
 // Normal equations over the masked pairs from the product tables (ascending k), Cramer.
+template <int PT, int... K>
+__device__ inline void fit_sums(const double* txx, const double* txy, const double* tyy, const double* tbx,
+                                const double* tby, unsigned long long mask, double& sxx, double& sxy,
+                                double& syy, double& bx, double& by, std::integer_sequence<int, K...>) {
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned int in = (unsigned int)((mask >> k) & 1ull);
+        sxx = sxx + keep_if(txx[k], in);
+        sxy = sxy + keep_if(txy[k], in);
+        syy = syy + keep_if(tyy[k], in);
+        bx = bx + keep_if(tbx[k], in);
+        by = by + keep_if(tby[k], in);
+    };
+    (one(std::integral_constant<int, K>{}), ...);
+}
+
 template <int PT>
-__device__ inline void fit_reg(const double* txx, const double* txy, const double* tyy, const double* tbx,
+__device__ __forceinline__ void fit_reg(const double* txx, const double* txy, const double* tyy, const double* tbx,
                                const double* tby, unsigned long long mask, double* z0, double* z1) {
     double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
-#pragma unroll
-    for (int k = 0; k < PT; ++k) {
-        const bool in = (mask >> k) & 1ull;
-        sxx = in ? sxx + txx[k] : sxx;
-        sxy = in ? sxy + txy[k] : sxy;
-        syy = in ? syy + tyy[k] : syy;
-        bx = in ? bx + tbx[k] : bx;
-        by = in ? by + tby[k] : by;
-    }
+    asm volatile("" ::: "memory");
+    fit_sums<PT>(txx, txy, tyy, tbx, tby, mask, sxx, sxy, syy, bx, by, std::make_integer_sequence<int, PT>{});
     const double det = sxx * syy - sxy * sxy;
     *z0 = (bx * syy - by * sxy) / det;
     *z1 = (by * sxx - bx * sxy) / det;
 }
 
-__device__ inline int block_sort_any(const double* v, int P, double* out, int tid, int nthr, int* cnt_sh) {
-    if (tid == 0) *cnt_sh = 0;
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) {
-        const double vk = v[k];
-        if (vk == vk) {
-            int rank = 0;
-            for (int j = 0; j < P; ++j) {
-                const double vj = v[j];
-                rank += (vj < vk) || (vj == vk && j < k);
-            }
-            out[rank] = vk;
-            atomicAdd(cnt_sh, 1);
+// wave-synchronous hand-off through LDS: one wave owns its LDS slab, LDS ops of a wave execute
+// in order, so only the compiler has to be kept from moving accesses across this point.
+#define WSYNC()                                               \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+// median of the non-NaN entries of v[0..P) (P <= 64), computed by one wave: lane k ranks v[k].
+__device__ inline double wave_nanmedian(const double* v, int P, double* srt, int lane) {
+    const double vk = lane < P ? v[lane] : dnan();
+    const bool ok = vk == vk;
+    const int m = __popcll(__ballot(ok));
+    if (ok) {
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const double vj = v[j];
+            rank += (vj < vk) || (vj == vk && j < lane);
         }
+        srt[rank] = vk;
     }
-    __syncthreads();
-    return *cnt_sh;
+    WSYNC();
+    double med = dnan();
+    if (m > 0) med = (m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5;
+    WSYNC();
+    return med;
 }
 
+// FAST-LTS with ONE WAVE PER UNIT: the starts are swept in rounds of 64 lanes, the candidate
+// peel-off / refinement / finish stay inside the wave (shuffles + the wave's own LDS slab), so
+// there is no workgroup barrier and no idle wave during the serial tail.
 template <int PT>
-__global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits) {
+__global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nunits, int slab_doubles) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
-    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-    const int u = blockIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int u = blockIdx.x * 4 + wv;
+    if (u >= nunits) return;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band];
     constexpr int P = PT;
@@ -606,13 +662,14 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
     const int h = a.h;
     const int64_t o = (int64_t)band * a.vector_len + w;
 
-    double* tauv = sm;            // [P]
+    double* base = sm + (size_t)wv * slab_doubles;
+    double* tauv = base;
     double* y = tauv + P;
     double* X0 = y + P;
     double* X1 = X0 + P;
     double* x0 = X1 + P;
     double* x1 = x0 + P;
-    double* txx = x1 + P;         // X0*X0, X0*X1, X1*X1, X0*y, X1*y (standardised)
+    double* txx = x1 + P;
     double* txy = txx + P;
     double* tyy = txy + P;
     double* tbx = tyy + P;
@@ -623,14 +680,12 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
     double* z0S = objS + S;
     double* z1S = z0S + S;
     double* cres = z1S + S;       // [NBLS_MAX_CAND][3]
-    double* wminv = cres + 3 * NBLS_MAX_CAND;      // [8]
-    int* wmins = (int*)(wminv + 8);                // [8]
-    int* cand = wmins + 8;                         // [NBLS_MAX_CAND]
-    int* misc = cand + NBLS_MAX_CAND;              // [4]
-    uint8_t* alive = (uint8_t*)(misc + 4);         // [S]
+    int* cand = (int*)(cres + 3 * NBLS_MAX_CAND);  // [NBLS_MAX_CAND]
+    uint8_t* alive = (uint8_t*)(cand + NBLS_MAX_CAND);   // [S]
     uint8_t* wsh = alive + S;                      // [P]
 
-    for (int k = tid; k < P; k += nthr) {
+    if (lane < P) {
+        const int k = lane;
         const double t = (double)a.lag[o * P + k] / a.fs;
         tauv[k] = t;
         tmp[k] = fabs(t);
@@ -640,26 +695,22 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
         x1[k] = a.xij[2 * k + 1];
         wsh[k] = 1;
     }
-    __syncthreads();
-    int m = block_sort_any(tmp, P, srt, tid, nthr, misc);
-    const double med = (m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5;
-    const double tmad = 1.4826 * med;
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) tmp[k] = a.cmax[o * P + k];
-    __syncthreads();
-    m = block_sort_any(tmp, P, srt, tid, nthr, misc);
-    if (tid == 0)
-        a.mdccm[o] = m == 0 ? dnan() : ((m & 1) ? srt[(m - 1) / 2] : (srt[m / 2 - 1] + srt[m / 2]) * 0.5);
-    __syncthreads();
-    if (tmad == 0.0) {
-        if (tid == 0) {
+    WSYNC();
+    const double tmad = 1.4826 * wave_nanmedian(tmp, P, srt, lane);
+    if (lane < P) tmp[lane] = a.cmax[o * P + lane];
+    WSYNC();
+    const double md = wave_nanmedian(tmp, P, srt, lane);
+    if (lane == 0) a.mdccm[o] = md;
+    if (tmad == 0.0) {     // "data spike" [R]: not processed
+        if (lane == 0) {
             a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
             a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
         }
-        for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = 1;
+        if (lane < P) a.wts[o * P + lane] = 1;
         return;
     }
-    for (int k = tid; k < P; k += nthr) {
+    if (lane < P) {
+        const int k = lane;
         const double yk = tauv[k] / tmad;
         const double c0 = X0[k], c1 = X1[k];
         y[k] = yk;
@@ -669,10 +720,11 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
         tbx[k] = c0 * yk;
         tby[k] = c1 * yk;
     }
-    __syncthreads();
+    WSYNC();
 
-    // ---- elemental starts ----
-    for (int s = tid; s < ((S + nthr - 1) / nthr) * nthr; s += nthr) {
+    // ---- elemental starts, 64 per round ----
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
         if (s < S) {
             unsigned long long sm_ = 0ull;
 #pragma unroll
@@ -704,14 +756,14 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
             alive[s] = (obj == obj) && obj < __builtin_inf();
         }
     }
-    __syncthreads();
+    WSYNC();
 
-    // ---- peel off the ncand best distinct starts: arg-min over (obj, s), knock out duplicates ----
+    // ---- peel off the ncand best distinct starts ----
     int nc = 0;
     for (int it = 0; it < a.ncand; ++it) {
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
-        for (int s = tid; s < S; s += nthr) {
+        for (int s = lane; s < S; s += 64) {
             if (alive[s]) {
                 const double ov = objS[s];
                 if (ov < bv || (ov == bv && s < bs)) { bv = ov; bs = s; }
@@ -722,28 +774,18 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
             const int os = __shfl_xor(bs, off, 64);
             if (ov < bv || (ov == bv && os < bs)) { bv = ov; bs = os; }
         }
-        if (lane == 0) { wminv[wv] = bv; wmins[wv] = bs; }
-        __syncthreads();
-        bv = wminv[0];
-        bs = wmins[0];
-        for (int q = 1; q < nwv; ++q) {
-            const double ov = wminv[q];
-            const int os = wmins[q];
-            if (ov < bv || (ov == bv && os < bs)) { bv = ov; bs = os; }
-        }
-        if (bs == 0x7fffffff) break;      // nothing alive (uniform: every lane read the same words)
+        if (bs == 0x7fffffff) break;      // nothing alive (wave-uniform after the butterfly)
         const double w0 = z0S[bs], w1 = z1S[bs];
-        __syncthreads();                  // everyone has read wmin*/the winner before they change
-        for (int s = tid; s < S; s += nthr)
+        for (int s = lane; s < S; s += 64)
             if (alive[s] && objS[s] == bv && z0S[s] == w0 && z1S[s] == w1) alive[s] = 0;
-        if (tid == 0) cand[nc] = bs;
+        if (lane == 0) cand[nc] = bs;
         ++nc;
-        __syncthreads();
+        WSYNC();
     }
-    __syncthreads();
+    WSYNC();
     // ---- refine, one candidate per lane ----
-    if (tid < nc) {
-        double z0 = z0S[cand[tid]], z1 = z1S[cand[tid]];
+    if (lane < nc) {
+        double z0 = z0S[cand[lane]], z1 = z1S[cand[lane]];
         RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
         double pobj = 0.0, cobj = __builtin_inf();
         if (!sel.ok) cobj = dnan();
@@ -760,12 +802,12 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
                 pobj = cobj;
             }
         }
-        cres[3 * tid] = cobj;
-        cres[3 * tid + 1] = z0;
-        cres[3 * tid + 2] = z1;
+        cres[3 * lane] = cobj;
+        cres[3 * lane + 1] = z0;
+        cres[3 * lane + 2] = z1;
     }
-    __syncthreads();
-    if (tid == 0) {
+    WSYNC();
+    if (lane == 0) {
         double zr0 = dnan(), zr1 = dnan();
         double best = __builtin_inf();
         for (int c = 0; c < nc; ++c)
@@ -823,24 +865,28 @@ __global__ __launch_bounds__(512) void solve_lts_fast_kernel(SArgs a, int nunits
             a.z[2 * o + 1] = zf1;
         }
     }
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = wsh[k];
+    WSYNC();
+    if (lane < P) a.wts[o * P + lane] = wsh[lane];
 }
 
-size_t lts_fast_lds_bytes(int P, int S) {
-    size_t b = (size_t)(13 * P + 3 * S + 3 * NBLS_MAX_CAND + 8) * sizeof(double);
-    b += (size_t)(8 + NBLS_MAX_CAND + 4) * sizeof(int);
+int lts_wave_slab_doubles(int P, int S) {
+    size_t b = (size_t)(13 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
+    b += (size_t)NBLS_MAX_CAND * sizeof(int);
     b += (size_t)S + P;
-    return (b + 15) & ~(size_t)15;
+    b = (b + 15) & ~(size_t)15;
+    return (int)(b / sizeof(double));
 }
 
 template <int PT>
 hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits) {
-    const int S = a.nstarts;
-    int nthr = ((S + 63) / 64) * 64;
-    if (nthr > 512) nthr = 512;
-    const size_t shm = lts_fast_lds_bytes(PT, S);
-    hipLaunchKernelGGL((solve_lts_fast_kernel<PT>), dim3(nunits), dim3(nthr), shm, h->stream, a, nunits);
+    const int slab = lts_wave_slab_doubles(PT, a.nstarts);
+    const size_t shm = (size_t)slab * 4 * sizeof(double);
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)solve_lts_wave_kernel<PT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((solve_lts_wave_kernel<PT>), dim3((nunits + 3) / 4), dim3(256), shm, h->stream, a, nunits, slab);
     return hipGetLastError();
 }
 
