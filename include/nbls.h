@@ -99,7 +99,8 @@ int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx
  *   winlen/wininc[nbands]       window length / hop in samples
  *   vector_len                  row length of the result grids (>= max windows per band)
  *   lts                         NULL -> ordinary least squares
- *   xcorr_impl                  0 auto, 1 plain VALU kernel, 2 f64-MFMA kernel
+ *   xcorr_impl                  0 auto, 1 plain VALU kernel, 2 f64-MFMA kernel,
+ *                               3 int8-MFMA screening + FP64 verification
  */
 int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections,
               int32_t zero_phase, const double* taper_left, const double* taper_right,
@@ -146,6 +147,13 @@ int nbls_run(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsection
 /* Debug / self-test: run one f64 MFMA 16x16x4 on caller data (a[64], b[64] one value per
  * lane) and return the 256 accumulator values as out[lane*4 + reg]. */
 int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double* out);
+/* Same for one int8 MFMA 16x16x64: a[64][4], b[64][4] packed dwords (16 int8 per lane),
+ * out[lane*4 + reg] int32. */
+int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32_t* out);
+
+/* Developer statistic of the int8 screening correlator (last unit batch): out4 = {ordered pairs,
+ * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
+int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ EXPORTS = [
     'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
     'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
-    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64',
+    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -81,6 +81,8 @@ def load_library(path=None):
     lib.nbls_get_timings.argtypes = [vp, C.POINTER(Timings)]
     lib.nbls_run.argtypes = plan_args + fetch_args
     lib.nbls_probe_mfma_f64.argtypes = [vp, dp, dp, dp]
+    lib.nbls_probe_mfma_i8.argtypes = [vp, ip, ip, ip]
+    lib.nbls_debug_screen_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         if name not in ('nbls_destroy', 'nbls_last_error'):
             getattr(lib, name).restype = C.c_int
@@ -236,6 +238,19 @@ class Handle:
         self._chk(self.lib.nbls_get_timings(self._h, C.byref(t)))
         return dict(filter_ms=t.filter_ms, xcorr_ms=t.xcorr_ms, solve_ms=t.solve_ms,
                     total_ms=t.total_ms, xcorr_launches=t.xcorr_launches)
+
+    def screen_stats(self):
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.nbls_debug_screen_stats(self._h, out))
+        return dict(pairs=out[0], overflow=out[1], candidates=out[2], max_candidates=out[3])
+
+    def probe_mfma_i8(self, a, b):
+        """a, b: (64, 16) int8 per-lane fragments -> (64, 4) int32 accumulators."""
+        a = np.ascontiguousarray(a, dtype=np.int8).view(np.int32).reshape(64, 4)
+        b = np.ascontiguousarray(b, dtype=np.int8).view(np.int32).reshape(64, 4)
+        out = np.empty((64, 4), dtype=np.int32)
+        self._chk(self.lib.nbls_probe_mfma_i8(self._h, _iptr(a), _iptr(b), _iptr(out)))
+        return out
 
     def probe_mfma_f64(self, a, b):
         a = _f64(a); b = _f64(b)

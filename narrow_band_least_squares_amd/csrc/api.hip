@@ -133,7 +133,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
                     h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -289,6 +289,20 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         h->cap_units = cells * P;
     }
 
+    if (xcorr_impl == 3) {
+        int S_, PFB_, CSB_, CSA_, WP_;
+        size_t lds_;
+        if (!nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_))
+            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..16 channels and a window that fits LDS");
+        // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
+        int64_t batch = (int64_t)(96ll << 20) / ((int64_t)h->nchans * 2 * WP_);
+        if (batch < 64) batch = 64;
+        if (batch > U) batch = U > 0 ? U : 1;
+        h->screen_batch = batch;
+        if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
+        if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * 4 * sizeof(double)))) return rc;
+        if ((rc = ensure(h, &h->d_cand, &h->cap_cand, (size_t)batch * h->nchans * h->nchans * 32 * sizeof(int32_t)))) return rc;
+    }
     h->lts = lts != nullptr;
     { const char* e = getenv("NBLS_LTS_IMPL"); h->lts_impl = e ? atoi(e) : 0; }
     if (lts) {
@@ -428,6 +442,47 @@ int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double
     HIPCHK(h, nbls_launch_probe_mfma(h, da, db, dout));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, dout, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return NBLS_OK;
+}
+
+int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
+    // out4 = {ordered pairs in the last batch, pairs whose candidate buffer overflowed,
+    //         total candidates, max candidates}  (developer statistic of the int8 screening path)
+    if (!h || !out4) return NBLS_ERR_ARG;
+    if (!h->d_cand || h->screen_batch <= 0) return fail(h, NBLS_ERR_STATE, "no screening run yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int N = h->nchans;
+    const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
+    std::vector<int32_t> c((size_t)last * N * N * 32);
+    HIPCHK(h, hipMemcpy(c.data(), h->d_cand, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (int64_t u = 0; u < last; ++u)
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                if (i == j) continue;
+                const int32_t* e = &c[((u * N + i) * N + j) * 32];
+                out4[0] += 1;
+                out4[1] += e[1] != 0;          // interval and/or list overflow
+                out4[2] += e[0];
+                if (e[0] > out4[3]) out4[3] = e[0];
+            }
+    return NBLS_OK;
+}
+
+int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32_t* out) {
+    if (!h || !a || !b || !out) return NBLS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void**)&da, 256 * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&db, 256 * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&dout, 256 * sizeof(int)));
+    HIPCHK(h, hipMemcpy(da, a, 256 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(db, b, 256 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, nbls_launch_probe_mfma_i8(h, da, db, dout));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, dout, 256 * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return NBLS_OK;
 }

@@ -61,6 +61,13 @@ struct nbls_handle {
     uint8_t* d_wts = nullptr;      // [B][VL][P]
     size_t cap_filt = 0, cap_cstate = 0, cap_res = 0, cap_units = 0, cap_bands = 0;
 
+    // ---- int8 screening correlator (xcorr_screen.hip) ----
+    int8_t* d_qbuf = nullptr;      // [batch][N][2][WP]
+    double* d_qmeta = nullptr;     // [batch][N][4]
+    int32_t* d_cand = nullptr;     // [batch][N][N][16]
+    size_t cap_qbuf = 0, cap_qmeta = 0, cap_cand = 0;
+    int64_t screen_batch = 0;
+
     // ---- LTS ----
     bool lts = false;
     int lts_impl = 0;              // 0 auto, 1 generic kernel (NBLS_LTS_IMPL env, for A/B tests)
@@ -82,3 +89,6 @@ hipError_t nbls_launch_filter(nbls_handle* h);
 hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
+bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds);
+hipError_t nbls_launch_xcorr_screen(nbls_handle* h);
+hipError_t nbls_launch_probe_mfma_i8(nbls_handle* h, const int* da, const int* db, int* dout);

@@ -262,6 +262,7 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     if (h->nunits == 0) return hipSuccess;
+    if (h->xcorr_impl == 3) return nbls_launch_xcorr_screen(h);   // int8 screening + FP64 verification
     h->tim.xcorr_launches = 1;
     // f64-MFMA kernel: needs one wave per channel (N <= 16) and the N-channel window in LDS
     const int N = h->nchans;

@@ -1,0 +1,491 @@
+// Cross-correlation lag pick by INT8 matrix-core screening + exact FP64 verification.
+//
+// Same contract as xcorr.hip (replaces LsBeam.correlate of lts_array): for every
+// (unit, pair) the first arg-max over all 2W-1 lags of np.correlate(x_i, x_j, 'full') and the
+// normalised maximum.  The arg-max is found WITHOUT evaluating every lag in FP64:
+//
+//  1. quantize  each channel window is scaled by its own max|x| to 15-bit integers q (|q| <= 16256)
+//               and split into two int8 limbs, q = 128*hi + lo, lo in [-64,63], hi in [-127,127].
+//  2. screen    the integer correlation I[d] = sum_n q_i[n+d] q_j[n] is computed EXACTLY for all lags
+//               with v_mfma_i32_16x16x64_i8 (four limb products, int32 accumulators, recombined as
+//               16384*HH + 128*(HL+LH) + LL).  Because |x*Q/s - q| <= 1/2, the true (scaled)
+//               correlation differs from I[d] by at most
+//                   eps = (sum|q_i| + sum|q_j|)/2 + W/4
+//               for every lag, so the true arg-max is among the lags with I[d] >= max I - 2 eps.
+//               Each lane keeps the few lags of its accumulator rows that pass that test against its
+//               running maximum; an LDS atomic max + filter leaves the candidate list per ordered pair.
+//  3. verify    one wave per (unit, pair) evaluates the candidates' correlations in FP64 from the
+//               filtered trace and takes the first maximum.  If a candidate buffer overflowed (flat
+//               correlation, dead channel) the wave falls back to evaluating every lag in FP64.
+//
+// The result is the FP64 arg-max (up to FP64 rounding ties, as for any summation order) at a small
+// fraction of the FP64 work: the screening runs on the int8 matrix pipe, ~64x the FP64 MFMA rate per
+// instruction, x1/4 for the limb products.
+//
+// Tile mapping (as in xcorr_mfma_kernel): rows r = 16 consecutive lags, columns c = (partner j,
+// 16-lag block s), K = 64 samples per MFMA:
+//     A[r][k] = q_i[n' + k + r + D0]   (16 byte-shifted copies of the sliding channel in LDS, so that
+//                                       every lane's 16-byte fragment is an aligned ds_read_b128)
+//     B[k][c] = q_j(c)[n' + k - 16 s(c)]
+// One workgroup per (unit, sliding channel i); its four waves share the tile steps; two tile steps are
+// processed together so that the B fragments are reused (LDS read bandwidth is the limiter: each
+// fragment pair feeds four MFMAs).
+#include "nbls_internal.h"
+
+namespace {
+
+constexpr int QMAX = 16256;      // 127 * 128
+constexpr int KOUT = 28;         // candidates kept per ordered pair
+constexpr int NSLOT = 6;         // candidate slots per lane
+constexpr int CSTRIDE = KOUT + 4;   // count, flags (1 interval, 2 list overflow), kk_lo, kk_hi, kk[KOUT]
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct QArgs {
+    const double* filt;
+    int64_t npts_pad;
+    int nchans;
+    const int32_t* Wb;
+    const int32_t* incb;
+    const int32_t* unit_off;
+    const int32_t* unit_band;
+    int u0, nu;               // unit batch
+    int WP;                   // padded window bytes (multiple of 16)
+    int8_t* qbuf;             // [nu][N][2][WP]
+    double* qmeta;            // [nu][N][4]  ss, L1q, smax, 0
+    // screen
+    int S, PFB, CSB, CSA;
+    int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
+    // verify
+    int npairs;
+    const int32_t* pair;
+    int vector_len;
+    int32_t* lag;
+    double* cmax;
+};
+
+// ------------------------------------------------------------------ 1. quantize
+__global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = a.nchans;
+    if (item >= a.nu * N) return;
+    const int ul = item / N, ch = item % N;
+    const int u = a.u0 + ul;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int W = a.Wb[band];
+    const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
+    double mx = 0.0, ss = 0.0;
+    for (int n = lane; n < W; n += 64) {
+        const double v = src[n];
+        mx = fmax(mx, fabs(v));
+        ss += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, off, 64));
+        ss += __shfl_xor(ss, off, 64);
+    }
+    const double scale = (mx > 0.0 && mx < __builtin_inf()) ? (double)QMAX / mx : 0.0;
+    int8_t* qh = a.qbuf + ((int64_t)ul * N + ch) * 2 * a.WP;
+    int8_t* ql = qh + a.WP;
+    long long l1 = 0;
+    for (int g = lane; g < a.WP / 16; g += 64) {
+        unsigned int ph[4] = {0, 0, 0, 0}, pl[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = g * 16 + e;
+            int q = 0;
+            if (n < W) q = (int)rint(src[n] * scale);
+            q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
+            const int lo = ((q + 64) & 127) - 64;
+            const int hi = (q - lo) >> 7;
+            l1 += q < 0 ? -q : q;
+            ph[e >> 2] |= (unsigned int)(hi & 0xff) << (8 * (e & 3));
+            pl[e >> 2] |= (unsigned int)(lo & 0xff) << (8 * (e & 3));
+        }
+        *(uint4*)(qh + g * 16) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *(uint4*)(ql + g * 16) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) l1 += __shfl_xor(l1, off, 64);
+    if (lane == 0) {
+        double* m = a.qmeta + ((int64_t)ul * N + ch) * 4;
+        m[0] = ss;
+        m[1] = (double)l1;
+        m[2] = mx;
+        m[3] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ 2. screen
+__device__ inline unsigned int alignbyte(unsigned int hi, unsigned int lo, unsigned int sh) {
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+__global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
+    extern __shared__ unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int N = a.nchans;
+    // keep the N workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so
+    // that the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
+    const int b = blockIdx.x;
+    const int grp = b / (8 * N), rem = b % (8 * N);
+    const int ul = grp * 8 + (rem & 7);
+    const int ci = rem >> 3;                         // sliding channel
+    if (ul >= a.nu) return;
+    const int u = a.u0 + ul;
+    const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
+    const int W = __builtin_amdgcn_readfirstlane(a.Wb[band]);      // wave-uniform: keeps the K loop scalar
+    const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
+
+    unsigned char* Bh = lds;                         // [N][CSB]
+    unsigned char* Bl = Bh + (size_t)N * CSB;        // [N][CSB]
+    unsigned char* Ah = Bl + (size_t)N * CSB;        // [16][CSA]
+    unsigned char* Al = Ah + (size_t)16 * CSA;       // [16][CSA]
+    // per-partner running maximum shared by the whole workgroup (a lower bound of the final maximum,
+    // so pruning against it is safe); without it a lane that only ever sees a slowly rising tail keeps
+    // every value as a "candidate" of its own small maximum and overflows its slots
+    long long* gmax = (long long*)(Al + (size_t)16 * CSA);     // [16]
+    if (tid < 16) gmax[tid] = (long long)0x8000000000000000ull;
+
+    // ---- stage the partners' limbs (zero padded) ----
+    const int gB = CSB / 16;
+    for (int item = tid; item < 2 * N * gB; item += blockDim.x) {
+        const int limb = item / (N * gB);
+        const int r2 = item % (N * gB);
+        const int ch = r2 / gB, g = r2 % gB;
+        const int m = g * 16 - PFB;                  // sample index of the first byte of this group
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m >= 0 && m < WP)
+            v = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
+        *(uint4*)((limb ? Bl : Bh) + (size_t)ch * CSB + g * 16) = v;
+    }
+    __syncthreads();
+    // ---- 16 byte-shifted copies of the sliding channel: A_r[m] = q_i[m + r] ----
+    const int gA = CSA / 16;
+    for (int item = tid; item < 2 * gA; item += blockDim.x) {
+        const int limb = item / gA, g = item % gA;
+        const unsigned char* srcb = (limb ? Bl : Bh) + (size_t)ci * CSB + PFB + g * 16;
+        unsigned int sdw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (PFB + g * 16 + 32 <= CSB) {
+            const uint4 lo4 = *(const uint4*)srcb;
+            const uint4 hi4 = *(const uint4*)(srcb + 16);
+            sdw[0] = lo4.x; sdw[1] = lo4.y; sdw[2] = lo4.z; sdw[3] = lo4.w;
+            sdw[4] = hi4.x; sdw[5] = hi4.y; sdw[6] = hi4.z; sdw[7] = hi4.w;
+        }
+        unsigned char* dst = (limb ? Al : Ah) + g * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = r >> 2, rb = r & 3;
+            uint4 o;
+            o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
+            o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
+            o.z = alignbyte(sdw[rw + 3], sdw[rw + 2], rb);
+            o.w = alignbyte(sdw[rw + 4], sdw[rw + 3], rb);
+            *(uint4*)(dst + (size_t)r * CSA) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- lane roles ----
+    const int c = lane & 15, g = lane >> 4;
+    const int ncol = (N - 1) * S;
+    const bool colvalid = c < ncol;
+    const int cc = colvalid ? c : 0;                 // idle columns mirror column 0 (LDS broadcast)
+    const int jj = cc % (N - 1);
+    const int s = cc / (N - 1);
+    const int j = jj + (jj >= ci ? 1 : 0);
+    const double* mi = a.qmeta + ((int64_t)ul * N + ci) * 4;
+    const double* mj = a.qmeta + ((int64_t)ul * N + j) * 4;
+    const double theta = (mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0;
+    const unsigned char* pAh = Ah + (size_t)(lane & 15) * CSA + 16 * g;   // + n' + D0
+    const unsigned char* pAl = Al + (size_t)(lane & 15) * CSA + 16 * g;
+    const unsigned char* pBh = Bh + (size_t)j * CSB + PFB + 16 * g - 16 * s;   // + n'
+    const unsigned char* pBl = Bl + (size_t)j * CSB + PFB + 16 * g - 16 * s;
+
+    double lmax = -__builtin_inf();
+    double sv[NSLOT];
+    int sd[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) { sv[q] = -__builtin_inf(); sd[q] = 0; }
+    int ilo = 0x7fffffff, ihi = -1;      // lag interval that absorbs what does not fit the slots
+    const int step = 16 * S;
+    const int ntile = (W + step - 1) / step;
+    const int npair = (ntile + 1) / 2;
+    // tile pairs get cheaper with p (K range W - D0): deal them to the waves in snake order
+    const int nw = blockDim.x >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    for (int rnd = 0; rnd * nw < npair; ++rnd) {
+        const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
+        if (p >= npair) continue;
+        const int D0 = 2 * p * step;
+        v4i c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c02 = {0, 0, 0, 0}, c03 = {0, 0, 0, 0};
+        v4i c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0}, c12 = {0, 0, 0, 0}, c13 = {0, 0, 0, 0};
+        const int klen = W - D0;
+        const unsigned char* qa_h = pAh + D0;
+        const unsigned char* qa_l = pAl + D0;
+        // software pipeline: the next K step's six fragments are in flight while the eight MFMAs of
+        // the current one issue (the LDS images are padded, so the last prefetch reads zeros)
+        v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
+        v4i a0h = *(const v4i*)(qa_h), a0l = *(const v4i*)(qa_l);
+        v4i a1h = *(const v4i*)(qa_h + step), a1l = *(const v4i*)(qa_l + step);
+        for (int n0 = 0; n0 < klen; n0 += 64) {
+            const v4i nbh = *(const v4i*)(pBh + n0 + 64);
+            const v4i nbl = *(const v4i*)(pBl + n0 + 64);
+            const v4i na0h = *(const v4i*)(qa_h + n0 + 64);
+            const v4i na0l = *(const v4i*)(qa_l + n0 + 64);
+            const v4i na1h = *(const v4i*)(qa_h + n0 + 64 + step);
+            const v4i na1l = *(const v4i*)(qa_l + n0 + 64 + step);
+            c00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0h, bh, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0h, bl, c01, 0, 0, 0);
+            c02 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0l, bh, c02, 0, 0, 0);
+            c03 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0l, bl, c03, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1h, bh, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1h, bl, c11, 0, 0, 0);
+            c12 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1l, bh, c12, 0, 0, 0);
+            c13 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1l, bl, c13, 0, 0, 0);
+            bh = nbh; bl = nbl; a0h = na0h; a0l = na0l; a1h = na1h; a1l = na1l;
+        }
+        const v4i acc[2][4] = {{c00, c01, c02, c03}, {c10, c11, c12, c13}};
+        if (colvalid) {
+            const double gm = (double)gmax[jj];
+            if (gm > lmax) lmax = gm;
+            const double lmax_in = lmax;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int d = D0 + t * step + 16 * s + 4 * g + reg;   // i32 C/D: row = 4*(lane>>4) + reg
+                    if (d < W) {
+                        const double v = 16384.0 * (double)acc[t][0][reg]
+                                         + 128.0 * (double)(acc[t][1][reg] + acc[t][2][reg])
+                                         + (double)acc[t][3][reg];
+                        if (v >= lmax - theta) {
+                            if (v > lmax) lmax = v;
+                            const double thr = lmax - theta;
+                            bool placed = false;
+#pragma unroll
+                            for (int q = 0; q < NSLOT; ++q) {
+                                const bool take = !placed && sv[q] < thr;   // free or stale slot
+                                sv[q] = take ? v : sv[q];
+                                sd[q] = take ? d : sd[q];
+                                placed = placed || take;
+                            }
+                            if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }
+                        }
+                    }
+                }
+            }
+            if (lmax > lmax_in) atomicMax(&gmax[jj], (long long)lmax);
+        }
+    }
+    __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
+    long long* Mj = (long long*)lds;                // [16]
+    int* cnt = (int*)(Mj + 16);                     // [16]
+    int* klo = cnt + 16;                            // [16] interval in np.correlate index space
+    int* khi = klo + 16;                            // [16]
+    int* lst = khi + 16;                            // [16][KOUT]
+    if (tid < 16) { Mj[tid] = (long long)0x8000000000000000ull; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
+    __syncthreads();
+    if (colvalid && lmax > -__builtin_inf()) atomicMax(&Mj[jj], (long long)lmax);
+    if (colvalid && ihi >= 0) {
+        const int k1 = (ci < j) ? (W - 1 + ilo) : (W - 1 - ihi);
+        const int k2 = (ci < j) ? (W - 1 + ihi) : (W - 1 - ilo);
+        atomicMin(&klo[jj], k1);
+        atomicMax(&khi[jj], k2);
+    }
+    __syncthreads();
+    if (colvalid) {
+        const double thr = (double)Mj[jj] - theta;
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            if (sv[q] >= thr) {
+                const int pos = atomicAdd(&cnt[jj], 1);
+                if (pos < KOUT) lst[jj * KOUT + pos] = (ci < j) ? (W - 1 + sd[q]) : (W - 1 - sd[q]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < (N - 1) * CSTRIDE) {
+        const int pj = tid / CSTRIDE, e = tid % CSTRIDE;
+        const int jabs = pj + (pj >= ci ? 1 : 0);
+        int32_t* out = a.cand + (((int64_t)ul * N + ci) * N + jabs) * CSTRIDE;
+        const int n = cnt[pj];
+        int val;
+        if (e == 0) val = n < KOUT ? n : KOUT;
+        else if (e == 1) val = (khi[pj] >= 0 ? 1 : 0) | (n > KOUT ? 2 : 0);
+        else if (e == 2) val = klo[pj];
+        else if (e == 3) val = khi[pj];
+        else val = (e - 4 < n && e - 4 < KOUT) ? lst[pj * KOUT + e - 4] : 0;
+        out[e] = val;
+    }
+}
+
+// ------------------------------------------------------------------ 3. verify (FP64)
+__device__ inline bool better(double v1, int k1, double v2, int k2) {
+    return (v1 > v2) || (v1 == v2 && k1 < k2);
+}
+
+// Exact FP64 correlation values of up to four candidate indices at once (one wave; lanes stride the
+// samples, the partner sample is loaded once for the four).  Unused entries carry kk = -1.
+__device__ inline void wave_dot4(const double* xa, const double* xb, int W, const int (&kk)[4], int lane,
+                                 double (&out)[4]) {
+    int d[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = kk[q] - (W - 1);
+    for (int n = lane; n < W; n += 64) {
+        const double vb = xb[n];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = n + d[q];
+            const double va = (kk[q] >= 0 && m >= 0 && m < W) ? xa[m] : 0.0;
+            acc[q] = __builtin_fma(va, vb, acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        out[q] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int P = a.npairs, N = a.nchans;
+    if (item >= a.nu * P) return;
+    const int ul = item / P, k = item % P;
+    const int u = a.u0 + ul;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int W = a.Wb[band];
+    const int64_t t0 = (int64_t)w * a.incb[band];
+    const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
+    const double* xa = a.filt + ((int64_t)band * N + ci) * a.npts_pad + t0;
+    const double* xb = a.filt + ((int64_t)band * N + cj) * a.npts_pad + t0;
+    const double ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
+    const double ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
+    const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
+    const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+    double best = -__builtin_inf();
+    int bestk = 0x7fffffff;
+    if (ssa == 0.0 || ssb == 0.0) {          // dead channel: every lag is 0, np.argmax gives index 0
+        best = 0.0;
+        bestk = 0;
+    } else {
+        // work list = the two candidate lists, then the two overflow intervals (or everything)
+        const int n1 = l1[0], n2 = l2[0];
+        const bool full = ((l1[1] | l2[1]) & 2) || (n1 + n2 == 0 && !((l1[1] | l2[1]) & 1));
+        int r0lo = 0, r0hi = -1, r1lo = 0, r1hi = -1;
+        if (full) { r0lo = 0; r0hi = 2 * W - 2; }
+        else {
+            if (l1[1] & 1) { r0lo = l1[2]; r0hi = l1[3]; }
+            if (l2[1] & 1) { r1lo = l2[2]; r1hi = l2[3]; }
+        }
+        const int nlist = full ? 0 : n1 + n2;
+        const int nr0 = r0hi >= r0lo ? r0hi - r0lo + 1 : 0;
+        const int nr1 = r1hi >= r1lo ? r1hi - r1lo + 1 : 0;
+        const int total = nlist + nr0 + nr1;
+        for (int q0 = 0; q0 < total; q0 += 4) {
+            int kk[4];
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = q0 + q;
+                int val = -1;
+                if (idx < nlist) val = idx < n1 ? l1[4 + idx] : l2[4 + idx - n1];
+                else if (idx < nlist + nr0) val = r0lo + (idx - nlist);
+                else if (idx < total) val = r1lo + (idx - nlist - nr0);
+                kk[q] = val;
+            }
+            wave_dot4(xa, xb, W, kk, lane, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (kk[q] >= 0 && better(v[q], kk[q], best, bestk)) { best = v[q]; bestk = kk[q]; }
+        }
+    }
+    if (lane == 0) {
+        const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
+        a.lag[o] = (W - 1) - bestk;
+        a.cmax[o] = best / sqrt(ssa * ssb);
+    }
+}
+
+__global__ void probe_mfma_i8_kernel(const int* a, const int* b, int* out) {
+    const int lane = threadIdx.x;
+    v4i av = {a[lane * 4], a[lane * 4 + 1], a[lane * 4 + 2], a[lane * 4 + 3]};
+    v4i bv = {b[lane * 4], b[lane * 4 + 1], b[lane * 4 + 2], b[lane * 4 + 3]};
+    v4i acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc, 0, 0, 0);
+    out[lane * 4 + 0] = acc[0];
+    out[lane * 4 + 1] = acc[1];
+    out[lane * 4 + 2] = acc[2];
+    out[lane * 4 + 3] = acc[3];
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+// Eligibility + LDS size of the screening path.
+bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds) {
+    const int N = h->nchans;
+    if (N < 3 || N > 16 || h->maxW < 64) return false;
+    *S = 16 / (N - 1);
+    *PFB = 16 * (*S - 1);
+    *WP = round_up(h->maxW, 16);
+    int csb = *PFB + *WP + 192;
+    csb = round_up(csb, 16);
+    while ((csb / 16) % 16 != 1) csb += 16;         // channel stride == 1 (mod 16) sixteen-byte slots
+    int csa = *WP + 320;
+    csa = round_up(csa, 16);
+    while ((csa / 16) % 16 != 2) csa += 16;         // copy stride == 2 (mod 16): conflict-free ds_read_b128
+    *CSB = csb;
+    *CSA = csa;
+    *lds = (size_t)2 * N * csb + (size_t)32 * csa + 128;
+    return *lds <= 160 * 1024 && *lds >= 1024;
+}
+
+hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
+    QArgs a{};
+    size_t lds = 0;
+    if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds)) return hipErrorInvalidValue;
+    const int N = h->nchans;
+    a.filt = h->d_filt;
+    a.npts_pad = h->npts_pad;
+    a.nchans = N;
+    a.Wb = h->d_W;
+    a.incb = h->d_inc;
+    a.unit_off = h->d_unit_off;
+    a.unit_band = h->d_unit_band;
+    a.qbuf = h->d_qbuf;
+    a.qmeta = h->d_qmeta;
+    a.cand = h->d_cand;
+    a.npairs = h->npairs;
+    a.pair = h->d_pair;
+    a.vector_len = h->vector_len;
+    a.lag = h->d_lag;
+    a.cmax = h->d_cmax;
+    hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int64_t launches = 0;
+    for (int64_t u0 = 0; u0 < h->nunits; u0 += h->screen_batch) {
+        a.u0 = (int)u0;
+        a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
+        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), 0, h->stream, a);
+        const int ngrp = (a.nu + 7) / 8;
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * N), dim3(512), lds, h->stream, a);
+        hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
+        ++launches;
+    }
+    h->tim.xcorr_launches = launches;
+    return hipGetLastError();
+}
+
+hipError_t nbls_launch_probe_mfma_i8(nbls_handle* h, const int* da, const int* db, int* dout) {
+    hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(1), dim3(64), 0, h->stream, da, db, dout);
+    return hipGetLastError();
+}

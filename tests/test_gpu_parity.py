@@ -45,6 +45,48 @@ def test_mfma_f64_layout():
     np.testing.assert_array_equal(got, D)
 
 
+def test_mfma_i8_layout():
+    """i8 16x16x64: A row = lane & 15, B col = lane & 15, lane's 16 bytes are K-group lane >> 4;
+    D[i][j] at lane = j + 16*(i//4), reg = i % 4 (the i32/f32 C/D map, unlike f64)."""
+    rng = np.random.default_rng(2)
+    A = rng.integers(-128, 128, size=(16, 64)).astype(np.int8)
+    B = rng.integers(-128, 128, size=(64, 16)).astype(np.int8)
+    a = np.zeros((64, 16), dtype=np.int8); b = np.zeros((64, 16), dtype=np.int8)
+    for lane in range(64):
+        a[lane] = A[lane & 15, 16 * (lane >> 4):16 * (lane >> 4) + 16]
+        b[lane] = B[16 * (lane >> 4):16 * (lane >> 4) + 16, lane & 15]
+    out = engine.get_handle().probe_mfma_i8(a, b)
+    D = A.astype(np.int64) @ B.astype(np.int64)
+    got = np.zeros((16, 16), dtype=np.int64)
+    for lane in range(64):
+        for reg in range(4):
+            got[4 * (lane >> 4) + reg, lane & 15] = out[lane, reg]
+    np.testing.assert_array_equal(got, D)
+
+
+def test_int8_screening_correlator_matches_fp64():
+    """xcorr_impl=3 (int8 MFMA screening + FP64 verification) against the f64-MFMA kernel: identical
+    lags on every (band, window, pair), maxima to rounding; including a dead channel (all lags tie)."""
+    c = _cfg('cfg3', 0.03)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    data = data.copy()
+    data[3, 5000:9000] = 0.0                    # some windows see a dead element
+    edges = [(0.1, 0.12), (0.2, 0.5), (1.0, 3.0), (4.0, 8.0)]
+    wl = [30.0, 30.0, 20.0, 10.0]
+    kw = dict(want_lag=True, want_cmax=True)
+    r64 = engine.process(data, fs, t0, c['rij'], edges, wl, 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
+    r8 = engine.process(data, fs, t0, c['rij'], edges, wl, 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=3, **kw)
+    np.testing.assert_array_equal(r8.lag, r64.lag)
+    np.testing.assert_allclose(r8.cmax, r64.cmax, rtol=1e-12, atol=1e-15)
+    for k in ('vel', 'baz', 'weights'):
+        np.testing.assert_array_equal(getattr(r8, k), getattr(r64, k))
+    c6 = _cfg('cfg2', 0.1)
+    d6, fs6, t6 = engine.stream_to_array(c6['st'])
+    a = engine.process(d6, fs6, t6, c6['rij'], [(0.5, 2.0)], [30.0], 0.5, 1.0, 'cheby1', 2, 0.01, xcorr_impl=2, **kw)
+    b = engine.process(d6, fs6, t6, c6['rij'], [(0.5, 2.0)], [30.0], 0.5, 1.0, 'cheby1', 2, 0.01, xcorr_impl=3, **kw)
+    np.testing.assert_array_equal(a.lag, b.lag)
+
+
 @pytest.mark.parametrize('ftype,fmin,fmax', [('butter', 0.5, 2.0), ('cheby1', 0.1, 0.5), ('butter', 0.1, 0.16)])
 def test_filter_data_parity(oracle, ftype, fmin, fmax):
     c = _cfg('cfg1b', 1.0)

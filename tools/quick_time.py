@@ -29,6 +29,8 @@ def main():
         print('%s scale=%g impl=%d units=%d wall=%.3fs filter=%.2fms xcorr=%.2fms solve=%.2fms total=%.2fms -> %.0f solves/s (device)'
               % (name, scale, impl, U, wall, tm['filter_ms'], tm['xcorr_ms'], tm['solve_ms'], tm['total_ms'],
                  U / (tm['total_ms'] * 1e-3)), flush=True)
+    if impl == 3:
+        print('screen stats (last batch):', h.screen_stats())
     n = int(res.nwin[len(edges) // 2])
     print('mid band: median baz %.3f vel %.4f mdccm %.3f' % (np.nanmedian(res.baz[len(edges) // 2, :n]),
           np.nanmedian(res.vel[len(edges) // 2, :n]), np.nanmedian(res.mdccm[len(edges) // 2, :n])))
