@@ -32,6 +32,7 @@ from narrow_band_least_squares_amd import dist, engine, planner, synthetic  # no
 from narrow_band_least_squares_amd.helpers import get_freqlist  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (AMD datasheet; the guide lists none)
+I8_MFMA_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: int8 MFMA = 2x the bf16 dense rate (~2.5 PF) per clock
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -46,7 +47,7 @@ def cpu_task(args):
     return len(out[0])
 
 
-def cpu_baseline(c, edges, budget_s=20.0):
+def cpu_baseline(c, edges, budget_s=10.0):
     """Oracle ("port") timed on the host cores on a bounded sample: one band per core, the first
     `seconds` of the trace, sized from a probe so that the whole leg takes about `budget_s`."""
     from joblib import Parallel, delayed
@@ -140,12 +141,15 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    xc, fl, sv = [], [], []
+    xc, fl, sv, scr, qz, vf = [], [], [], [], [], []
+    impl_used = 0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
         tm = h.timings()
         xc.append(tm['xcorr_ms']); fl.append(tm['filter_ms']); sv.append(tm['solve_ms'])
+        scr.append(tm['screen_ms']); qz.append(tm['quantize_ms']); vf.append(tm['verify_ms'])
+        impl_used = tm['xcorr_impl']
     sync_all()
     elapsed = time.perf_counter() - t_start
     if use_dist:
@@ -159,8 +163,13 @@ def main():
         xcorr_ms = float(np.mean(xc))
         flop_unit = 2.0 * P * float(W) * float(W)
         bytes_unit = 8.0 * nchans * inc + 40.0 + math.ceil(P / 8)
-        achieved_tf = flop_unit * units_rank / (xcorr_ms * 1e-3) / 1e12
-        achieved_gbs = bytes_unit * units_rank / (xcorr_ms * 1e-3) / 1e9
+        # dominant kernel: the int8-MFMA screening kernel (impl 3), else the f64-MFMA / VALU correlator
+        if impl_used == 3:
+            kern, kern_ms, peak = 'screen_kernel (int8 MFMA screening of the full-lag correlation)', float(np.mean(scr)), I8_MFMA_PEAK_TOPS
+        else:
+            kern, kern_ms, peak = 'xcorr_mfma_kernel (f64 MFMA)' if impl_used == 2 else 'xcorr_simple_kernel', xcorr_ms, FP64_MFMA_PEAK_TFLOPS
+        achieved_tf = flop_unit * units_rank / (kern_ms * 1e-3) / 1e12
+        achieved_gbs = bytes_unit * units_rank / (kern_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
@@ -180,10 +189,15 @@ def main():
                        'lts_starts': None if lts is None else int(lts['starts'].shape[0]),
                        'parallelism': 'bands sharded over %d GPU(s), one all-gather of the grids' % world,
                        'scale': args.scale},
-            'stage_ms': {'filter': float(np.mean(fl)), 'xcorr': xcorr_ms, 'solve': float(np.mean(sv))},
-            'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'kernel': 'xcorr', 'flop_per_unit': flop_unit, 'launch_ms': xcorr_ms},
+            'stage_ms': {'filter': float(np.mean(fl)), 'xcorr': xcorr_ms, 'solve': float(np.mean(sv)),
+                         'xcorr_quantize': float(np.mean(qz)), 'xcorr_screen': float(np.mean(scr)),
+                         'xcorr_verify': float(np.mean(vf))},
+            'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved_tf / peak, 'traffic': traffic, 'kernel': kern,
+                         'flop_per_unit': flop_unit, 'kernel_ms_per_step': kern_ms,
+                         'launches_per_step': int(h.timings()['xcorr_launches']),
+                         'note': 'achieved = algorithmic 2*P*W^2 flop per unit x units / kernel time; the screening '
+                                 'kernel issues 4 int8 limb products per algorithmic multiply-add'},
             'roofline_hbm': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'bytes_per_unit': bytes_unit},
         }

@@ -70,7 +70,12 @@ typedef struct {
     double xcorr_ms;
     double solve_ms;
     double total_ms;
-    int64_t xcorr_launches;
+    int64_t xcorr_launches;   /* unit batches of the correlation stage                         */
+    double quantize_ms;       /* int8 screening path only: sums over the batches               */
+    double screen_ms;         /*   the int8-MFMA screening kernel (dominant kernel)            */
+    double verify_ms;         /*   the FP64 verification kernel                                */
+    int32_t xcorr_impl;       /* correlator actually used: 1 VALU, 2 f64 MFMA, 3 int8 screening */
+    int32_t reserved;
 } nbls_timings;
 
 int nbls_version(void);

@@ -136,6 +136,7 @@ void nbls_destroy(nbls_handle* h) {
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -151,6 +152,10 @@ int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t 
     HIPCHK(h, hipMemcpy2DAsync(h->d_trace, pad * sizeof(double), trace, npts * sizeof(double),
                                npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->nchans != nchans && h->d_xij) {      // a geometry of another array size is stale
+        (void)hipFree(h->d_xij); h->d_xij = nullptr;
+        h->npairs = 0;
+    }
     h->nchans = nchans;
     h->npts = npts;
     h->npts_pad = pad;
@@ -289,11 +294,19 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         h->cap_units = cells * P;
     }
 
+    {   // resolve "auto": int8 screening when the array/window fit it, else f64 MFMA, else plain VALU
+        int S_, PFB_, CSB_, CSA_, WP_;
+        size_t lds_;
+        const bool ok = h->d_xij && nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_);
+        if (xcorr_impl == 3 && !ok)
+            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..16 channels and a window that fits LDS");
+        if (xcorr_impl == 0 && ok) xcorr_impl = 3;
+        h->xcorr_impl = xcorr_impl;
+    }
     if (xcorr_impl == 3) {
         int S_, PFB_, CSB_, CSA_, WP_;
         size_t lds_;
-        if (!nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_))
-            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..16 channels and a window that fits LDS");
+        (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_);
         // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
         int64_t batch = (int64_t)(96ll << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
@@ -361,6 +374,16 @@ int nbls_sync(nbls_handle* h) {
         HIPCHK(h, hipEventElapsedTime(&s, h->ev[2], h->ev[3]));
         HIPCHK(h, hipEventElapsedTime(&t, h->ev[0], h->ev[3]));
         h->tim.filter_ms = f; h->tim.xcorr_ms = x; h->tim.solve_ms = s; h->tim.total_ms = t;
+        h->tim.quantize_ms = h->tim.screen_ms = h->tim.verify_ms = 0.0;
+        for (int b = 0; b + 3 < h->bev_used; b += 4) {
+            float q = 0, sc = 0, v = 0;
+            HIPCHK(h, hipEventElapsedTime(&q, h->bev[b], h->bev[b + 1]));
+            HIPCHK(h, hipEventElapsedTime(&sc, h->bev[b + 1], h->bev[b + 2]));
+            HIPCHK(h, hipEventElapsedTime(&v, h->bev[b + 2], h->bev[b + 3]));
+            h->tim.quantize_ms += q; h->tim.screen_ms += sc; h->tim.verify_ms += v;
+        }
+        h->bev_used = 0;
+        h->tim.xcorr_impl = h->xcorr_impl_used;
         h->ev_valid = false;
     }
     return NBLS_OK;

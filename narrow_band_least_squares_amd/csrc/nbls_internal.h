@@ -81,6 +81,9 @@ struct nbls_handle {
     bool prof = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    std::vector<hipEvent_t> bev;   // per-batch events of the screening path (4 per batch)
+    int bev_used = 0;
+    int xcorr_impl_used = 0;       // 1 VALU, 2 f64 MFMA, 3 int8 screening
     nbls_timings tim{};
 };
 

@@ -262,7 +262,7 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     if (h->nunits == 0) return hipSuccess;
-    if (h->xcorr_impl == 3) return nbls_launch_xcorr_screen(h);   // int8 screening + FP64 verification
+    if (h->xcorr_impl == 3) { h->xcorr_impl_used = 3; return nbls_launch_xcorr_screen(h); }   // int8 screening + FP64 verification
     h->tim.xcorr_launches = 1;
     // f64-MFMA kernel: needs one wave per channel (N <= 16) and the N-channel window in LDS
     const int N = h->nchans;
@@ -282,11 +282,13 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
         hipError_t e = hipFuncSetAttribute((const void*)xcorr_mfma_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m);
         if (e != hipSuccess) return e;
+        h->xcorr_impl_used = 2;
         hipLaunchKernelGGL(xcorr_mfma_kernel, dim3((unsigned)h->nunits), dim3(64 * N), shm_m, h->stream, a);
         return hipGetLastError();
     }
     const int64_t nblocks = h->nunits * h->npairs;
     const size_t shm = (size_t)2 * h->maxW * sizeof(double);
+    h->xcorr_impl_used = 1;
     hipLaunchKernelGGL(xcorr_simple_kernel, dim3((unsigned)nblocks), dim3(256), shm, h->stream, a);
     return hipGetLastError();
 }

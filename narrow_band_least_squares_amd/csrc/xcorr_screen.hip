@@ -31,6 +31,7 @@
 // processed together so that the B fragments are reused (LDS read bandwidth is the limiter: each
 // fragment pair feeds four MFMAs).
 #include "nbls_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -55,6 +56,8 @@ struct QArgs {
     double* qmeta;            // [nu][N][4]  ss, L1q, smax, 0
     // screen
     int S, PFB, CSB, CSA;
+    int8_t boff[16];          // per-partner LDS skew in 16-byte slots (bank-conflict-free B reads)
+    int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
     int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
     // verify
     int npairs;
@@ -122,7 +125,31 @@ __device__ inline unsigned int alignbyte(unsigned int hi, unsigned int lo, unsig
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
-__global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
+// order-preserving float <-> int (for integer atomicMax on LDS)
+__device__ inline int f2ord(float f) {
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ inline float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
+
+#define MFMA_I8(A_, B_, C_) C_ = __builtin_amdgcn_mfma_i32_16x16x64_i8(A_, B_, C_, 0, 0, 0)
+// the four limb products of one tile: HH, HL, LH, LL
+#define TILE4(AH, AL, C0, C1, C2, C3) \
+    MFMA_I8(AH, bh, C0);              \
+    MFMA_I8(AH, bl, C1);              \
+    MFMA_I8(AL, bh, C2);              \
+    MFMA_I8(AL, bl, C3)
+
+constexpr int TB = 4;            // tile steps processed together (they share the B fragments)
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ inline v4i ld_frag64(const unsigned char* p) {     // two aligned 8-byte LDS reads
+    const v2i lo = *(const v2i*)p;
+    const v2i hi = *(const v2i*)(p + 8);
+    return (v4i){lo[0], lo[1], hi[0], hi[1]};
+}
+
+__global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -138,157 +165,167 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
     const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
     const int W = __builtin_amdgcn_readfirstlane(a.Wb[band]);      // wave-uniform: keeps the K loop scalar
     const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
+    const int NP = N - 1;
 
-    unsigned char* Bh = lds;                         // [N][CSB]
-    unsigned char* Bl = Bh + (size_t)N * CSB;        // [N][CSB]
-    unsigned char* Ah = Bl + (size_t)N * CSB;        // [16][CSA]
-    unsigned char* Al = Ah + (size_t)16 * CSA;       // [16][CSA]
+    // LDS: partner images [NP][2 limbs][CSB] (partner jj skewed by boff[jj] sixteen-byte slots so that
+    // the B fragment reads are bank-conflict free), then the 16 shifted copies of the sliding channel
+    unsigned char* Bimg = lds;
+    unsigned char* Ah = Bimg + (size_t)NP * 2 * CSB;   // [8][CSA]  copies shifted by 0..7 bytes
+    unsigned char* Al = Ah + (size_t)8 * CSA;          // [8][CSA]
     // per-partner running maximum shared by the whole workgroup (a lower bound of the final maximum,
     // so pruning against it is safe); without it a lane that only ever sees a slowly rising tail keeps
     // every value as a "candidate" of its own small maximum and overflows its slots
-    long long* gmax = (long long*)(Al + (size_t)16 * CSA);     // [16]
-    if (tid < 16) gmax[tid] = (long long)0x8000000000000000ull;
+    int* gmax = (int*)(Al + (size_t)8 * CSA);        // [16] order-preserving int image of a float
+    if (tid < 16) gmax[tid] = (int)0x80000000;
 
-    // ---- stage the partners' limbs (zero padded) ----
-    const int gB = CSB / 16;
-    for (int item = tid; item < 2 * N * gB; item += blockDim.x) {
-        const int limb = item / (N * gB);
-        const int r2 = item % (N * gB);
-        const int ch = r2 / gB, g = r2 % gB;
+    // ---- stage the partners' limbs (zero padded front and back) ----
+    const int gB = (CSB - 256) / 16;                 // groups written per image (skew room excluded)
+    if (!(a.ablate & 2))
+    for (int item = tid; item < 2 * NP * gB; item += 256) {
+        const int limb = item / (NP * gB);
+        const int r2 = item % (NP * gB);
+        const int pj = r2 / gB, g = r2 % gB;
+        const int ch = pj + (pj >= ci ? 1 : 0);
         const int m = g * 16 - PFB;                  // sample index of the first byte of this group
         uint4 v = make_uint4(0, 0, 0, 0);
         if (m >= 0 && m < WP)
             v = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
-        *(uint4*)((limb ? Bl : Bh) + (size_t)ch * CSB + g * 16) = v;
+        *(uint4*)(Bimg + ((size_t)pj * 2 + limb) * CSB + 16 * a.boff[pj] + g * 16) = v;
     }
-    __syncthreads();
-    // ---- 16 byte-shifted copies of the sliding channel: A_r[m] = q_i[m + r] ----
-    const int gA = CSA / 16;
-    for (int item = tid; item < 2 * gA; item += blockDim.x) {
+    // ---- 8 byte-shifted copies of the sliding channel: A_r[m] = q_i[m + r], r = 0..7.  A lane's
+    //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
+    const int gA = CSA / 8;
+    if (!(a.ablate & 2))
+    for (int item = tid; item < 2 * gA; item += 256) {
         const int limb = item / gA, g = item % gA;
-        const unsigned char* srcb = (limb ? Bl : Bh) + (size_t)ci * CSB + PFB + g * 16;
-        unsigned int sdw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (PFB + g * 16 + 32 <= CSB) {
-            const uint4 lo4 = *(const uint4*)srcb;
-            const uint4 hi4 = *(const uint4*)(srcb + 16);
-            sdw[0] = lo4.x; sdw[1] = lo4.y; sdw[2] = lo4.z; sdw[3] = lo4.w;
-            sdw[4] = hi4.x; sdw[5] = hi4.y; sdw[6] = hi4.z; sdw[7] = hi4.w;
+        const int8_t* src = a.qbuf + (((int64_t)ul * N + ci) * 2 + limb) * WP;
+        unsigned int sdw[4] = {0, 0, 0, 0};
+        if (g * 8 < WP) {
+            const uint2 lo2 = *(const uint2*)(src + g * 8);
+            sdw[0] = lo2.x; sdw[1] = lo2.y;
         }
-        unsigned char* dst = (limb ? Al : Ah) + g * 16;
+        if (g * 8 + 8 < WP) {
+            const uint2 hi2 = *(const uint2*)(src + g * 8 + 8);
+            sdw[2] = hi2.x; sdw[3] = hi2.y;
+        }
+        unsigned char* dst = (limb ? Al : Ah) + g * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const int rw = r >> 2, rb = r & 3;
-            uint4 o;
+            uint2 o;
             o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
             o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
-            o.z = alignbyte(sdw[rw + 3], sdw[rw + 2], rb);
-            o.w = alignbyte(sdw[rw + 4], sdw[rw + 3], rb);
-            *(uint4*)(dst + (size_t)r * CSA) = o;
+            *(uint2*)(dst + (size_t)r * CSA) = o;
         }
     }
     __syncthreads();
 
     // ---- lane roles ----
     const int c = lane & 15, g = lane >> 4;
-    const int ncol = (N - 1) * S;
+    const int ncol = NP * S;
     const bool colvalid = c < ncol;
     const int cc = colvalid ? c : 0;                 // idle columns mirror column 0 (LDS broadcast)
-    const int jj = cc % (N - 1);
-    const int s = cc / (N - 1);
+    const int jj = cc % NP;
+    const int s = cc / NP;
     const int j = jj + (jj >= ci ? 1 : 0);
     const double* mi = a.qmeta + ((int64_t)ul * N + ci) * 4;
     const double* mj = a.qmeta + ((int64_t)ul * N + j) * 4;
-    const double theta = (mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0;
-    const unsigned char* pAh = Ah + (size_t)(lane & 15) * CSA + 16 * g;   // + n' + D0
-    const unsigned char* pAl = Al + (size_t)(lane & 15) * CSA + 16 * g;
-    const unsigned char* pBh = Bh + (size_t)j * CSB + PFB + 16 * g - 16 * s;   // + n'
-    const unsigned char* pBl = Bl + (size_t)j * CSB + PFB + 16 * g - 16 * s;
+    // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
+    // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
+    const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
+                            ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
+    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0) * 1.0001 + 1.0e-6 * iabs);
+    const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
+    const unsigned char* pAl = Al + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);
+    const unsigned char* pBh = Bimg + ((size_t)jj * 2) * CSB + 16 * a.boff[jj] + PFB + 16 * g - 16 * s;   // + n'
+    const unsigned char* pBl = pBh + CSB;
 
-    double lmax = -__builtin_inf();
-    double sv[NSLOT];
+    float lmax = -__builtin_inff();
+    float sv[NSLOT];
     int sd[NSLOT];
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) { sv[q] = -__builtin_inf(); sd[q] = 0; }
+    for (int q = 0; q < NSLOT; ++q) { sv[q] = -__builtin_inff(); sd[q] = 0; }
     int ilo = 0x7fffffff, ihi = -1;      // lag interval that absorbs what does not fit the slots
     const int step = 16 * S;
     const int ntile = (W + step - 1) / step;
-    const int npair = (ntile + 1) / 2;
-    // tile pairs get cheaper with p (K range W - D0): deal them to the waves in snake order
+    const int ngrp4 = (ntile + TB - 1) / TB;
+    // tile groups get cheaper with p (K range W - D0): deal them to the waves in snake order
     const int nw = blockDim.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    for (int rnd = 0; rnd * nw < npair; ++rnd) {
+    for (int rnd = 0; rnd * nw < ngrp4; ++rnd) {
         const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
-        if (p >= npair) continue;
-        const int D0 = 2 * p * step;
+        if (p >= ngrp4) continue;
+        const int D0 = TB * p * step;
         v4i c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c02 = {0, 0, 0, 0}, c03 = {0, 0, 0, 0};
         v4i c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0}, c12 = {0, 0, 0, 0}, c13 = {0, 0, 0, 0};
+        v4i c20 = {0, 0, 0, 0}, c21 = {0, 0, 0, 0}, c22 = {0, 0, 0, 0}, c23 = {0, 0, 0, 0};
+        v4i c30 = {0, 0, 0, 0}, c31 = {0, 0, 0, 0}, c32 = {0, 0, 0, 0}, c33 = {0, 0, 0, 0};
         const int klen = W - D0;
         const unsigned char* qa_h = pAh + D0;
         const unsigned char* qa_l = pAl + D0;
-        // software pipeline: the next K step's six fragments are in flight while the eight MFMAs of
-        // the current one issue (the LDS images are padded, so the last prefetch reads zeros)
-        v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
-        v4i a0h = *(const v4i*)(qa_h), a0l = *(const v4i*)(qa_l);
-        v4i a1h = *(const v4i*)(qa_h + step), a1l = *(const v4i*)(qa_l + step);
-        for (int n0 = 0; n0 < klen; n0 += 64) {
-            const v4i nbh = *(const v4i*)(pBh + n0 + 64);
-            const v4i nbl = *(const v4i*)(pBl + n0 + 64);
-            const v4i na0h = *(const v4i*)(qa_h + n0 + 64);
-            const v4i na0l = *(const v4i*)(qa_l + n0 + 64);
-            const v4i na1h = *(const v4i*)(qa_h + n0 + 64 + step);
-            const v4i na1l = *(const v4i*)(qa_l + n0 + 64 + step);
-            c00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0h, bh, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0h, bl, c01, 0, 0, 0);
-            c02 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0l, bh, c02, 0, 0, 0);
-            c03 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0l, bl, c03, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1h, bh, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1h, bl, c11, 0, 0, 0);
-            c12 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1l, bh, c12, 0, 0, 0);
-            c13 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1l, bl, c13, 0, 0, 0);
-            bh = nbh; bl = nbl; a0h = na0h; a0l = na0l; a1h = na1h; a1l = na1l;
+        for (int n0 = (a.ablate & 1) ? klen : 0; n0 < klen; n0 += 64) {
+            const v4i bh = *(const v4i*)(pBh + n0);
+            const v4i bl = *(const v4i*)(pBl + n0);
+            const v4i a0h = ld_frag64(qa_h + n0);
+            const v4i a0l = ld_frag64(qa_l + n0);
+            const v4i a1h = ld_frag64(qa_h + n0 + step);
+            const v4i a1l = ld_frag64(qa_l + n0 + step);
+            const v4i a2h = ld_frag64(qa_h + n0 + 2 * step);
+            const v4i a2l = ld_frag64(qa_l + n0 + 2 * step);
+            const v4i a3h = ld_frag64(qa_h + n0 + 3 * step);
+            const v4i a3l = ld_frag64(qa_l + n0 + 3 * step);
+            TILE4(a0h, a0l, c00, c01, c02, c03);
+            TILE4(a1h, a1l, c10, c11, c12, c13);
+            TILE4(a2h, a2l, c20, c21, c22, c23);
+            TILE4(a3h, a3l, c30, c31, c32, c33);
         }
-        const v4i acc[2][4] = {{c00, c01, c02, c03}, {c10, c11, c12, c13}};
-        if (colvalid) {
-            const double gm = (double)gmax[jj];
-            if (gm > lmax) lmax = gm;
-            const double lmax_in = lmax;
+        const v4i acc[TB][4] = {{c00, c01, c02, c03}, {c10, c11, c12, c13}, {c20, c21, c22, c23}, {c30, c31, c32, c33}};
+        if (colvalid && !(a.ablate & 4)) {
+            // values in f32 (the int32 limb sums recombined; relative error <= 2^-22, covered by theta)
+            float v[TB * 4];
+            float gmx = -__builtin_inff();
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TB; ++t) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int d = D0 + t * step + 16 * s + 4 * g + reg;   // i32 C/D: row = 4*(lane>>4) + reg
-                    if (d < W) {
-                        const double v = 16384.0 * (double)acc[t][0][reg]
-                                         + 128.0 * (double)(acc[t][1][reg] + acc[t][2][reg])
-                                         + (double)acc[t][3][reg];
-                        if (v >= lmax - theta) {
-                            if (v > lmax) lmax = v;
-                            const double thr = lmax - theta;
-                            bool placed = false;
-#pragma unroll
-                            for (int q = 0; q < NSLOT; ++q) {
-                                const bool take = !placed && sv[q] < thr;   // free or stale slot
-                                sv[q] = take ? v : sv[q];
-                                sd[q] = take ? d : sd[q];
-                                placed = placed || take;
-                            }
-                            if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }
-                        }
-                    }
+                    const float x = 16384.0f * (float)acc[t][0][reg]
+                                    + 128.0f * (float)(acc[t][1][reg] + acc[t][2][reg]) + (float)acc[t][3][reg];
+                    v[t * 4 + reg] = d < W ? x : -__builtin_inff();
+                    gmx = fmaxf(gmx, v[t * 4 + reg]);
                 }
             }
-            if (lmax > lmax_in) atomicMax(&gmax[jj], (long long)lmax);
+            // publish this group's maximum first, then prune against the workgroup-wide running maximum
+            if (gmx > lmax) { lmax = gmx; atomicMax(&gmax[jj], f2ord(gmx)); }
+            const float gm = ord2f(gmax[jj]);
+            if (gm > lmax) lmax = gm;
+            const float thr = lmax - theta;
+#pragma unroll
+            for (int e = 0; e < TB * 4; ++e) {
+                if (v[e] >= thr) {
+                    const int d = D0 + (e >> 2) * step + 16 * s + 4 * g + (e & 3);
+                    bool placed = false;
+#pragma unroll
+                    for (int q = 0; q < NSLOT; ++q) {
+                        const bool take = !placed && sv[q] < thr;   // free or stale slot
+                        sv[q] = take ? v[e] : sv[q];
+                        sd[q] = take ? d : sd[q];
+                        placed = placed || take;
+                    }
+                    if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }
+                }
+            }
         }
     }
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
-    long long* Mj = (long long*)lds;                // [16]
-    int* cnt = (int*)(Mj + 16);                     // [16]
+    int* Mj = (int*)lds;                            // [16] ordered-int image of the maximum
+    int* cnt = Mj + 16;                             // [16]
     int* klo = cnt + 16;                            // [16] interval in np.correlate index space
     int* khi = klo + 16;                            // [16]
     int* lst = khi + 16;                            // [16][KOUT]
-    if (tid < 16) { Mj[tid] = (long long)0x8000000000000000ull; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
+    if (tid < 16) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
     __syncthreads();
-    if (colvalid && lmax > -__builtin_inf()) atomicMax(&Mj[jj], (long long)lmax);
+    if (colvalid && lmax > -__builtin_inff()) atomicMax(&Mj[jj], f2ord(lmax));
     if (colvalid && ihi >= 0) {
         const int k1 = (ci < j) ? (W - 1 + ilo) : (W - 1 - ihi);
         const int k2 = (ci < j) ? (W - 1 + ihi) : (W - 1 - ilo);
@@ -297,7 +334,7 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
     }
     __syncthreads();
     if (colvalid) {
-        const double thr = (double)Mj[jj] - theta;
+        const float thr = ord2f(Mj[jj]) - theta;
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             if (sv[q] >= thr) {
@@ -307,8 +344,8 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
         }
     }
     __syncthreads();
-    if (tid < (N - 1) * CSTRIDE) {
-        const int pj = tid / CSTRIDE, e = tid % CSTRIDE;
+    for (int item = tid; item < NP * CSTRIDE; item += 256) {
+        const int pj = item / CSTRIDE, e = item % CSTRIDE;
         const int jabs = pj + (pj >= ci ? 1 : 0);
         int32_t* out = a.cand + (((int64_t)ul * N + ci) * N + jabs) * CSTRIDE;
         const int n = cnt[pj];
@@ -430,6 +467,43 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
+// Per-partner skew (in 16-byte slots, mod 16) that makes the B-fragment ds_read_b128 of every lane
+// group conflict free: two lanes of a group may share a slot only if they read the same address.
+// Lane l reads partner jj(l), slot o[jj] + g - s; depth-first search over o[] (translation fixed by
+// o[0] = 0).  Falls back to o[jj] = jj (at most 2-way conflicts) if nothing is found.
+static bool boff_ok(const int* o, int upto, int NP, int S) {
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    for (int gi = 0; gi < 4; ++gi) {
+        int slot_addr[16];
+        for (int q = 0; q < 16; ++q) slot_addr[q] = -1000000;
+        for (int q = 0; q < 16; ++q) {
+            const int l = groups[gi][q];
+            int c = l & 15;
+            const int g = l >> 4;
+            if (c >= NP * S) c = 0;
+            const int jj = c % NP, s = c / NP;
+            if (jj > upto) continue;
+            const int addr = jj * 4096 + o[jj] + g - s;           // distinct partners never alias
+            const int slot = ((o[jj] + g - s) % 16 + 16) % 16;
+            if (slot_addr[slot] == -1000000) slot_addr[slot] = addr;
+            else if (slot_addr[slot] != addr) return false;
+        }
+    }
+    return true;
+}
+
+static bool boff_dfs(int* o, int jj, int NP, int S) {
+    if (jj == NP) return true;
+    for (int v = (jj == 0 ? 0 : 0); v < (jj == 0 ? 1 : 16); ++v) {
+        o[jj] = v;
+        if (boff_ok(o, jj, NP, S) && boff_dfs(o, jj + 1, NP, S)) return true;
+    }
+    return false;
+}
+
 // Eligibility + LDS size of the screening path.
 bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds) {
     const int N = h->nchans;
@@ -437,15 +511,14 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     *S = 16 / (N - 1);
     *PFB = 16 * (*S - 1);
     *WP = round_up(h->maxW, 16);
-    int csb = *PFB + *WP + 192;
-    csb = round_up(csb, 16);
-    while ((csb / 16) % 16 != 1) csb += 16;         // channel stride == 1 (mod 16) sixteen-byte slots
-    int csa = *WP + 320;
-    csa = round_up(csa, 16);
-    while ((csa / 16) % 16 != 2) csa += 16;         // copy stride == 2 (mod 16): conflict-free ds_read_b128
-    *CSB = csb;
+    // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
+    // row of room for the per-partner skew
+    *CSB = round_up(*PFB + *WP + 192, 256) + 256;
+    int csa = *WP + 144 + (TB - 1) * 16 * (*S);      // K round-up + read-ahead of the last tile of a group
+    csa = round_up(csa, 32);
+    while (csa % 256 != 32) csa += 32;               // copy stride == 32 B (mod 256): conflict-free ds_read_b64
     *CSA = csa;
-    *lds = (size_t)2 * N * csb + (size_t)32 * csa + 128;
+    *lds = (size_t)2 * (N - 1) * (*CSB) + (size_t)16 * csa + 128;
     return *lds <= 160 * 1024 && *lds >= 1024;
 }
 
@@ -469,18 +542,40 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.vector_len = h->vector_len;
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
+    { const char* e = getenv("NBLS_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    {
+        int o[16] = {0};
+        if (!boff_dfs(o, 0, N - 1, a.S))
+            for (int q = 0; q < 16; ++q) o[q] = q;
+        for (int q = 0; q < 16; ++q) a.boff[q] = (int8_t)o[q];
+    }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int64_t launches = 0;
+    const int64_t nbatch = (h->nunits + h->screen_batch - 1) / h->screen_batch;
+    if (h->prof) {
+        while ((int64_t)h->bev.size() < 4 * nbatch) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return hipErrorOutOfMemory;
+            h->bev.push_back(ev);
+        }
+    }
+    h->bev_used = 0;
     for (int64_t u0 = 0; u0 < h->nunits; u0 += h->screen_batch) {
         a.u0 = (int)u0;
         a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
+        hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
+        if (ev) (void)hipEventRecord(ev[0], h->stream);
         hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), 0, h->stream, a);
+        if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * N), dim3(512), lds, h->stream, a);
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * N), dim3(256), lds, h->stream, a);
+        if (ev) (void)hipEventRecord(ev[2], h->stream);
         hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
+        if (ev) (void)hipEventRecord(ev[3], h->stream);
         ++launches;
     }
+    if (h->prof) h->bev_used = (int)(4 * launches);
     h->tim.xcorr_launches = launches;
     return hipGetLastError();
 }
