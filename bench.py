@@ -85,7 +85,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    use_dist = world > 1
+    # under torch.distributed.run the RCCL path is used even for one rank (lets the N>1 code be
+    # rehearsed on a single GPU)
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('NBLS_BENCH_FORCE_DIST', '1') == '1')
     if use_dist:
         import torch
         import torch.distributed as td

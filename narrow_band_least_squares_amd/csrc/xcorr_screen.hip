@@ -68,9 +68,14 @@ struct QArgs {
 };
 
 // ------------------------------------------------------------------ 1. quantize
+// One wave per (unit, channel).  The window is read once from global memory with lane-contiguous
+// 8-byte loads into the wave's LDS slab (max |x| and sum x^2 on the way); each lane then quantises
+// runs of 16 consecutive samples from LDS and stores two 16-byte limb groups, so that both the reads
+// and the writes of the kernel are coalesced.
 __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ double qsm[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
     const int N = a.nchans;
     if (item >= a.nu * N) return;
     const int ul = item / N, ch = item % N;
@@ -79,9 +84,11 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     const int w = u - a.unit_off[band];
     const int W = a.Wb[band];
     const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
+    double* sm = qsm + (size_t)wv * a.WP;
     double mx = 0.0, ss = 0.0;
-    for (int n = lane; n < W; n += 64) {
-        const double v = src[n];
+    for (int n = lane; n < a.WP; n += 64) {
+        const double v = n < W ? src[n] : 0.0;
+        sm[n] = v;
         mx = fmax(mx, fabs(v));
         ss += v * v;
     }
@@ -97,9 +104,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
         unsigned int ph[4] = {0, 0, 0, 0}, pl[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int n = g * 16 + e;
-            int q = 0;
-            if (n < W) q = (int)rint(src[n] * scale);
+            int q = (int)rint(sm[g * 16 + e] * scale);
             q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
             const int lo = ((q + 64) & 127) - 64;
             const int hi = (q - lo) >> 7;
@@ -389,38 +394,25 @@ __device__ inline void wave_dot4(const double* xa, const double* xb, int W, cons
     }
 }
 
-__global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int P = a.npairs, N = a.nchans;
-    if (item >= a.nu * P) return;
-    const int ul = item / P, k = item % P;
-    const int u = a.u0 + ul;
-    const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
-    const int W = a.Wb[band];
-    const int64_t t0 = (int64_t)w * a.incb[band];
-    const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
-    const double* xa = a.filt + ((int64_t)band * N + ci) * a.npts_pad + t0;
-    const double* xb = a.filt + ((int64_t)band * N + cj) * a.npts_pad + t0;
-    const double ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
-    const double ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
-    const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
-    const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+// Verify one pair: xa/xb point at the two channel windows (LDS or global).  The two 32-int candidate
+// records are fetched with ONE load per lane (lanes 0-31: i->j record, 32-63: j->i) and read back with
+// wave-uniform shuffles, so the wave does not chase a chain of dependent global loads.
+__device__ inline void verify_pair(const double* xa, const double* xb, int W, int rec, double ssa, double ssb,
+                                   int lane, double* best_out, int* bestk_out) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
     if (ssa == 0.0 || ssb == 0.0) {          // dead channel: every lag is 0, np.argmax gives index 0
         best = 0.0;
         bestk = 0;
     } else {
-        // work list = the two candidate lists, then the two overflow intervals (or everything)
-        const int n1 = l1[0], n2 = l2[0];
-        const bool full = ((l1[1] | l2[1]) & 2) || (n1 + n2 == 0 && !((l1[1] | l2[1]) & 1));
+        const int n1 = __shfl(rec, 0, 64), f1 = __shfl(rec, 1, 64);
+        const int n2 = __shfl(rec, 32, 64), f2 = __shfl(rec, 33, 64);
+        const bool full = ((f1 | f2) & 2) || (n1 + n2 == 0 && !((f1 | f2) & 1));
         int r0lo = 0, r0hi = -1, r1lo = 0, r1hi = -1;
         if (full) { r0lo = 0; r0hi = 2 * W - 2; }
         else {
-            if (l1[1] & 1) { r0lo = l1[2]; r0hi = l1[3]; }
-            if (l2[1] & 1) { r1lo = l2[2]; r1hi = l2[3]; }
+            if (f1 & 1) { r0lo = __shfl(rec, 2, 64); r0hi = __shfl(rec, 3, 64); }
+            if (f2 & 1) { r1lo = __shfl(rec, 34, 64); r1hi = __shfl(rec, 35, 64); }
         }
         const int nlist = full ? 0 : n1 + n2;
         const int nr0 = r0hi >= r0lo ? r0hi - r0lo + 1 : 0;
@@ -433,7 +425,7 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const int idx = q0 + q;
                 int val = -1;
-                if (idx < nlist) val = idx < n1 ? l1[4 + idx] : l2[4 + idx - n1];
+                if (idx < nlist) val = __shfl(rec, idx < n1 ? 4 + idx : 36 + idx - n1, 64);
                 else if (idx < nlist + nr0) val = r0lo + (idx - nlist);
                 else if (idx < total) val = r1lo + (idx - nlist - nr0);
                 kk[q] = val;
@@ -444,6 +436,93 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
                 if (kk[q] >= 0 && better(v[q], kk[q], best, bestk)) { best = v[q]; bestk = kk[q]; }
         }
     }
+    *best_out = best;
+    *bestk_out = bestk;
+}
+
+// Block-per-unit variant: the N channel windows are staged once in LDS (N*W*8 bytes), the waves
+// share the unit's pairs.  Used when the windows fit; otherwise verify_kernel reads from global.
+__global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
+    extern __shared__ double vsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
+    const int P = a.npairs, N = a.nchans;
+    const int ul = blockIdx.x;
+    const int u = a.u0 + ul;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int W = a.Wb[band];
+    const int64_t t0 = (int64_t)w * a.incb[band];
+    // issue the candidate-record and norm loads of this wave's pairs first: their latency hides
+    // behind the window staging
+    int recs[4];
+    double ssA[4], ssB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = wv + q * nwv;
+        recs[q] = 0; ssA[q] = 0.0; ssB[q] = 0.0;
+        if (k < P) {
+            const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
+            const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
+            const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+            recs[q] = lane < 32 ? l1[lane] : l2[lane - 32];
+            ssA[q] = a.qmeta[((int64_t)ul * N + ci) * 4];
+            ssB[q] = a.qmeta[((int64_t)ul * N + cj) * 4];
+        }
+    }
+    for (int ch = wv; ch < N; ch += nwv) {
+        const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + t0;
+#pragma unroll 4
+        for (int n = lane; n < W; n += 64) vsm[(size_t)ch * W + n] = src[n];
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 * nwv + wv < P; k0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = wv + (k0 + q) * nwv;
+            if (k >= P) break;
+            const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
+            int rec = recs[q];
+            double ssa = ssA[q], ssb = ssB[q];
+            if (k0 > 0) {     // more than four pairs per wave (big arrays): load on demand
+                const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
+                const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+                rec = lane < 32 ? l1[lane] : l2[lane - 32];
+                ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
+                ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
+            }
+            double best;
+            int bestk;
+            verify_pair(vsm + (size_t)ci * W, vsm + (size_t)cj * W, W, rec, ssa, ssb, lane, &best, &bestk);
+            if (lane == 0) {
+                const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
+                a.lag[o] = (W - 1) - bestk;
+                a.cmax[o] = best / sqrt(ssa * ssb);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int P = a.npairs, N = a.nchans;
+    if (item >= a.nu * P) return;
+    const int ul = item / P, k = item % P;
+    const int u = a.u0 + ul;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band];
+    const int W = a.Wb[band];
+    const int64_t t0 = (int64_t)w * a.incb[band];
+    const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
+    const double ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
+    const double ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
+    double best;
+    int bestk;
+    const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
+    const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+    const int rec = lane < 32 ? l1[lane] : l2[lane - 32];
+    verify_pair(a.filt + ((int64_t)band * N + ci) * a.npts_pad + t0, a.filt + ((int64_t)band * N + cj) * a.npts_pad + t0,
+                W, rec, ssa, ssb, lane, &best, &bestk);
     if (lane == 0) {
         const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
         a.lag[o] = (W - 1) - bestk;
@@ -551,6 +630,11 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    const size_t vlds = (size_t)N * h->maxW * sizeof(double);
+    if (vlds <= 80 * 1024) {
+        e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
+        if (e != hipSuccess) return e;
+    }
     int64_t launches = 0;
     const int64_t nbatch = (h->nunits + h->screen_batch - 1) / h->screen_batch;
     if (h->prof) {
@@ -566,12 +650,15 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
         hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
-        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * a.WP * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * N), dim3(256), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
-        hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
+        if (vlds <= 80 * 1024)
+            hipLaunchKernelGGL(verify_lds_kernel, dim3(a.nu), dim3(512), vlds, h->stream, a);
+        else
+            hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);
         ++launches;
     }
