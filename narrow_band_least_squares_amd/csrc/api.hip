@@ -48,50 +48,64 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
     return 0;
 }
 
-// Zero-input one-chunk transition matrix M = A^C of the DF2T cascade (state order
-// [s1_0, s2_0, s1_1, s2_1, ...]), in long double.
-void chunk_transition(const double* sos, int S, int C, double* M) {
+// Host-side linear algebra of the DF2T cascade (state order [s1_0, s2_0, s1_1, s2_1, ...]), in long
+// double: one step is s' = A s + g x.  Returns, for a chunk of C samples and carry groups of G chunks,
+//   fw[t][d]    = (A^(C-1-t) g)[d]         zero-state end state  e = sum_t fw[t] x_t
+//   mpow[j]     = (A^C)^j, j = 0..G        chunk / group transitions
+void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
     const int D = 2 * S;
-    std::vector<long double> A(D * D, 0.0L), R(D * D, 0.0L), Tm(D * D);
-    for (int col = 0; col < D; ++col) {
-        std::vector<long double> st(D, 0.0L);
-        st[col] = 1.0L;
-        long double v = 0.0L;
+    typedef long double ld;
+    auto step = [&](std::vector<ld>& st, ld x) {
+        ld v = x;
         for (int s = 0; s < S; ++s) {
-            const long double b0 = sos[s * 6 + 0], b1 = sos[s * 6 + 1], b2 = sos[s * 6 + 2];
-            const long double a1 = sos[s * 6 + 4], a2 = sos[s * 6 + 5];
-            const long double y = b0 * v + st[2 * s];
-            const long double n1 = (b1 * v - a1 * y) + st[2 * s + 1];
-            const long double n2 = b2 * v - a2 * y;
+            const ld b0 = sos[s * 6 + 0], b1 = sos[s * 6 + 1], b2 = sos[s * 6 + 2];
+            const ld a1 = sos[s * 6 + 4], a2 = sos[s * 6 + 5];
+            const ld y = b0 * v + st[2 * s];
+            const ld n1 = (b1 * v - a1 * y) + st[2 * s + 1];
+            const ld n2 = b2 * v - a2 * y;
             st[2 * s] = n1;
             st[2 * s + 1] = n2;
             v = y;
         }
+    };
+    std::vector<ld> A(D * D), g(D, 0.0L);
+    for (int col = 0; col < D; ++col) {
+        std::vector<ld> st(D, 0.0L);
+        st[col] = 1.0L;
+        step(st, 0.0L);
         for (int r = 0; r < D; ++r) A[r * D + col] = st[r];
     }
-    for (int i = 0; i < D; ++i) R[i * D + i] = 1.0L;
-    int e = C;
-    std::vector<long double> B = A;
-    while (e > 0) {
-        if (e & 1) {
-            for (int i = 0; i < D; ++i)
-                for (int j = 0; j < D; ++j) {
-                    long double acc = 0.0L;
-                    for (int k = 0; k < D; ++k) acc += R[i * D + k] * B[k * D + j];
-                    Tm[i * D + j] = acc;
-                }
-            R = Tm;
-        }
+    step(g, 1.0L);
+    auto matvec = [&](const std::vector<ld>& Mx, const std::vector<ld>& v) {
+        std::vector<ld> o(D, 0.0L);
         for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                long double acc = 0.0L;
-                for (int k = 0; k < D; ++k) acc += B[i * D + k] * B[k * D + j];
-                Tm[i * D + j] = acc;
-            }
-        B = Tm;
-        e >>= 1;
+            for (int k = 0; k < D; ++k) o[i] += Mx[i * D + k] * v[k];
+        return o;
+    };
+    auto matmul = [&](const std::vector<ld>& X, const std::vector<ld>& Y) {
+        std::vector<ld> o(D * D, 0.0L);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j)
+                for (int k = 0; k < D; ++k) o[i * D + j] += X[i * D + k] * Y[k * D + j];
+        return o;
+    };
+    std::vector<ld> v = g;
+    for (int k = 0; k < C; ++k) {            // v = A^k g  ->  weight of sample t = C-1-k
+        for (int d = 0; d < D; ++d) fw[(size_t)(C - 1 - k) * D + d] = (double)v[d];
+        v = matvec(A, v);
     }
-    for (int i = 0; i < D * D; ++i) M[i] = (double)R[i];
+    std::vector<ld> M(D * D, 0.0L), B = A;   // M = A^C by squaring
+    for (int i = 0; i < D; ++i) M[i * D + i] = 1.0L;
+    for (int e = C; e > 0; e >>= 1) {
+        if (e & 1) M = matmul(M, B);
+        B = matmul(B, B);
+    }
+    std::vector<ld> Pw(D * D, 0.0L);
+    for (int i = 0; i < D; ++i) Pw[i * D + i] = 1.0L;
+    for (int j = 0; j <= G; ++j) {
+        for (int i = 0; i < D * D; ++i) mpow[(size_t)j * D * D + i] = (double)Pw[i];
+        Pw = matmul(Pw, M);
+    }
 }
 
 }  // namespace
@@ -133,7 +147,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
                     h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -249,9 +263,12 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
 
     int rc;
     const int D = 2 * nsections;
-    std::vector<double> M((size_t)nbands * D * D);
-    for (int b = 0; b < nbands; ++b)
-        chunk_transition(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, &M[(size_t)b * D * D]);
+    const int GG = NBLS_FILTER_GROUP;
+    std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
+    for (int b = 0; b < nbands && nsections > 0; ++b)
+        filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
+                      &FW[(size_t)b * NBLS_FILTER_CHUNK * D], &M[(size_t)b * (GG + 1) * D * D]);
+    if ((rc = alloc_copy(h, &h->d_fw, FW.data(), FW.size()))) return rc;
     if ((rc = alloc_copy(h, &h->d_sos, sos, (size_t)nbands * nsections * 6))) return rc;
     if (nsections == 0 && nbands != 1)
         return fail(h, NBLS_ERR_ARG, "nbls_plan: an unfiltered plan has exactly one band");
@@ -270,6 +287,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const size_t nseries = (size_t)nbands * h->nchans;
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
+    const size_t ngroups = (size_t)((h->nchunks + NBLS_FILTER_GROUP - 1) / NBLS_FILTER_GROUP);
+    if ((rc = ensure(h, &h->d_gend, &h->cap_gend, nseries * ngroups * D * sizeof(double)))) return rc;
+    if ((rc = ensure(h, &h->d_gin, &h->cap_gin, nseries * ngroups * D * sizeof(double)))) return rc;
     // results: one arena sized for [B][VL] grids
     const size_t cells = (size_t)nbands * vector_len;
     const size_t need = cells * sizeof(double);

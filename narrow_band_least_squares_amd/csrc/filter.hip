@@ -5,30 +5,33 @@
 // Butterworth band-pass or scipy.signal.sosfilt causal Chebyshev-I; stf.taper(0.01)).
 //
 // An IIR cascade is a recurrence in time, and there are only B*N independent series
-// (e.g. 384), far too few for 256 CUs.  So time is cut into chunks of NBLS_FILTER_CHUNK
-// samples, one chunk per lane, and the recurrence is carried across chunks by the affine
-// map of the 2S-dimensional DF2T state:
+// (e.g. 384), far too few for 256 CUs.  Time is cut into chunks of C = NBLS_FILTER_CHUNK
+// samples and the recurrence is carried across chunks through the affine map of the
+// 2S-dimensional DF2T state  s_out = M s_in + e  (M = A^C, e = zero-state end state):
 //
-//   phase 1  every chunk is filtered from a ZERO initial state; only its end state e_c is kept
-//   phase 2  per series, sequentially over chunks:  init_c = s;  s = M s + e_c   (M = A^C,
-//            the zero-input transition of one chunk, computed on the host)
-//   phase 3  every chunk is filtered again from init_c and the output is written
+//   states   e_c of every chunk: the zero-state end state is LINEAR in the chunk's samples,
+//            e_c = sum_t A^(C-1-t) g x_t, so it is a small GEMV with host-computed weights —
+//            one wave per chunk, lanes along time, fully coalesced, no recurrence.
+//   carry    hierarchical scan of s <- M s + e_c over the chunks of a series: groups of 64 chunks
+//            are scanned locally in parallel, the few group totals sequentially (powers of M from
+//            the host), the group-in state is folded into each chunk's start state by the next step.
+//   apply    every chunk is filtered by the real recurrence from its start state and written
+//            (one lane per chunk; 64-chunk x 32-sample tiles staged through LDS so that global
+//            accesses are 256-B row segments; the next tile is prefetched into registers while the
+//            current one is filtered).
 //
-// Inside a chunk the arithmetic is scipy's DF2T recurrence, un-fused (this file is built
-// with -ffp-contract=off), so the output differs from scipy.signal.sosfilt only by the
-// rounding of the carried states.  Zero-phase = the same three phases on the time-reversed
-// pass-1 output, in place.  The taper is multiplied in when the last pass writes.
-//
-// Memory access: lane <-> chunk means a lane's samples are 4 KiB apart, so each wave stages
-// a 64-chunk x 32-sample tile through LDS (row stride 33 doubles: conflict-free row reads):
-// global loads/stores move 256-B contiguous row segments, HBM sees every sample once per
-// phase.  HBM-bound; algorithmic traffic = (2 reads + 1 write) x 8 B per sample per pass.
+// Inside a chunk the arithmetic is scipy's DF2T recurrence, un-fused (this file is built with
+// -ffp-contract=off), so the output differs from scipy.signal.sosfilt only by the rounding of the
+// carried start states.  Zero-phase = the same steps on the time-reversed pass-1 output, in
+// place.  The taper is multiplied in when the last pass writes.  HBM-bound by construction:
+// 2 reads + 1 write of 8 B per sample per pass.
 #include "nbls_internal.h"
 
 namespace {
 
 constexpr int C = NBLS_FILTER_CHUNK;
 constexpr int T = NBLS_FILTER_TILE;
+constexpr int G = NBLS_FILTER_GROUP;
 
 struct FilterArgs {
     const double* in;
@@ -37,11 +40,16 @@ struct FilterArgs {
     double* out;
     int64_t out_stride;
     const double* sos;     // [B][S][6]
-    double* cstate;        // [nchunks][nseries][2S]
+    const double* fw;      // [B][C][2S]   state weights  w_t = A^(C-1-t) g
+    const double* mpow;    // [B][G+1][2S][2S]  powers of M = A^C
+    double* cstate;        // [nchunks][nseries][2S]   e_c, then local start states
+    double* gend;          // [ngroups][nseries][2S]   group totals
+    double* gin;           // [ngroups][nseries][2S]   state entering each group
     int nchans;
     int nseries;
     int64_t npts;
     int64_t nchunks;
+    int ngroups;
     int reverse;
     int final_pass;
     const double* tl;
@@ -49,8 +57,116 @@ struct FilterArgs {
     int taper_len;
 };
 
-template <int S, int PHASE>
-__global__ __launch_bounds__(64) void filter_chunk_kernel(FilterArgs a) {
+// ---- states: one wave per (series, chunk) ----
+template <int S>
+__global__ __launch_bounds__(256) void filter_state_kernel(FilterArgs a) {
+    constexpr int D = 2 * S;
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.y;
+    if (chunk >= a.nchunks) return;
+    const int band = q / a.nchans;
+    const double* in = a.in + (int64_t)(q % a.in_mod) * a.in_stride;
+    const double* fw = a.fw + (int64_t)band * C * D;
+    double acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.0;
+    const int64_t p0 = chunk * C;
+    if (p0 + C <= a.npts) {          // the end state of a partial last chunk is never used
+#pragma unroll
+        for (int k = 0; k < C / 64; ++k) {
+            const int t = k * 64 + lane;
+            const int64_t p = p0 + t;
+            const double x = in[a.reverse ? (a.npts - 1 - p) : p];
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += fw[t * D + d] * x;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        for (int off = 32; off > 0; off >>= 1) acc[d] += __shfl_xor(acc[d], off, 64);
+    if (lane == 0) {
+        double* st = a.cstate + (chunk * a.nseries + q) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) st[d] = acc[d];
+    }
+}
+
+// ---- carry, level 1: local scan inside each group of G chunks (lane per (group, series)) ----
+template <int S>
+__global__ void filter_carry_local_kernel(FilterArgs a) {
+    constexpr int D = 2 * S;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gi = blockIdx.y;
+    if (q >= a.nseries) return;
+    const int band = q / a.nchans;
+    const double* M = a.mpow + ((int64_t)band * (G + 1) + 1) * D * D;      // M^1
+    double m[D][D], s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        s[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) m[i][j] = M[i * D + j];
+    }
+    const int64_t c0 = (int64_t)gi * G;
+    const int64_t c1 = (c0 + G < a.nchunks) ? c0 + G : a.nchunks;
+    for (int64_t c = c0; c < c1; ++c) {
+        double* cur = a.cstate + (c * a.nseries + q) * D;
+        double e[D], sn[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) e[i] = cur[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) cur[i] = s[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double acc = e[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc += m[i][j] * s[j];
+            sn[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = sn[i];
+    }
+    double* ge = a.gend + ((int64_t)gi * a.nseries + q) * D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ge[i] = s[i];
+}
+
+// ---- carry, level 2: sequential over the groups (lane per series) ----
+template <int S>
+__global__ void filter_carry_groups_kernel(FilterArgs a) {
+    constexpr int D = 2 * S;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nseries) return;
+    const int band = q / a.nchans;
+    double s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = 0.0;
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        double* gin = a.gin + ((int64_t)gi * a.nseries + q) * D;
+        const double* ge = a.gend + ((int64_t)gi * a.nseries + q) * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) gin[i] = s[i];
+        const int64_t c0 = (int64_t)gi * G;
+        const int len = (int)((c0 + G < a.nchunks ? c0 + G : a.nchunks) - c0);
+        const double* Mg = a.mpow + ((int64_t)band * (G + 1) + len) * D * D;     // M^len
+        double sn[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double acc = ge[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc += Mg[i * D + j] * s[j];
+            sn[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = sn[i];
+    }
+}
+
+// ---- apply: recurrence from the chunk's start state, one lane per chunk ----
+template <int S>
+__global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
+    constexpr int D = 2 * S;
     __shared__ double tile[64][T + 1];
     const int lane = threadIdx.x;
     const int q = blockIdx.y;
@@ -72,31 +188,43 @@ __global__ __launch_bounds__(64) void filter_chunk_kernel(FilterArgs a) {
         s1[s] = 0.0;
         s2[s] = 0.0;
     }
-    if (PHASE == 3 && chunk < a.nchunks) {
-        const double* st = a.cstate + ((int64_t)chunk * a.nseries + q) * (2 * S);
+    if (chunk < a.nchunks) {
+        // start state = local prefix + M^j (state entering the group), j = index inside the group
+        const int gi = (int)(chunk / G), j = (int)(chunk % G);
+        const double* loc = a.cstate + (chunk * a.nseries + q) * D;
+        const double* gin = a.gin + ((int64_t)gi * a.nseries + q) * D;
+        const double* Mj = a.mpow + ((int64_t)band * (G + 1) + j) * D * D;
+        double st[D], gv[D];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            s1[s] = st[2 * s];
-            s2[s] = st[2 * s + 1];
+        for (int i = 0; i < D; ++i) gv[i] = gin[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double acc = loc[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Mj[i * D + k] * gv[k];
+            st[i] = acc;
         }
+#pragma unroll
+        for (int s = 0; s < S; ++s) { s1[s] = st[2 * s]; s2[s] = st[2 * s + 1]; }
     }
 
+    // tile (64 chunks x 32 samples): instruction i moves rows 2i, 2i+1 (256-B contiguous segments)
+    double pre[T];
+    auto fetch = [&](int ti) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int row = 2 * i + (lane >> 5);
+            const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + (lane & 31);
+            pre[i] = p < a.npts ? in[a.reverse ? (a.npts - 1 - p) : p] : 0.0;
+        }
+    };
+    fetch(0);
     for (int ti = 0; ti < C / T; ++ti) {
         if (chunk0 * C + (int64_t)ti * T >= a.npts) break;   // wave-uniform
-        // cooperative load: 2 rows x 32 samples per instruction, 256-B contiguous segments
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const int row = 2 * i + (lane >> 5);
-            const int col = lane & 31;
-            const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
-            double v = 0.0;
-            if (p < a.npts) {
-                const int64_t g = a.reverse ? (a.npts - 1 - p) : p;
-                v = in[g];
-            }
-            tile[row][col] = v;
-        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) tile[2 * i + (lane >> 5)][lane & 31] = pre[i];
         __syncthreads();
+        if (ti + 1 < C / T) fetch(ti + 1);                    // in flight while this tile is filtered
 #pragma unroll 4
         for (int t = 0; t < T; ++t) {
             double v = tile[lane][t];
@@ -107,83 +235,37 @@ __global__ __launch_bounds__(64) void filter_chunk_kernel(FilterArgs a) {
                 s2[s] = b2[s] * v - a2[s] * y;
                 v = y;
             }
-            if (PHASE == 3) tile[lane][t] = v;
+            tile[lane][t] = v;
         }
         __syncthreads();
-        if (PHASE == 3) {
 #pragma unroll 4
-            for (int i = 0; i < 32; ++i) {
-                const int row = 2 * i + (lane >> 5);
-                const int col = lane & 31;
-                const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
-                if (p < a.npts) {
-                    const int64_t g = a.reverse ? (a.npts - 1 - p) : p;
-                    double v = tile[row][col];
-                    if (a.final_pass) {
-                        if (g < a.taper_len) v = v * a.tl[g];
-                        else if (g >= a.npts - a.taper_len) v = v * a.tr[g - (a.npts - a.taper_len)];
-                    }
-                    out[g] = v;
+        for (int i = 0; i < T; ++i) {
+            const int row = 2 * i + (lane >> 5);
+            const int col = lane & 31;
+            const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
+            if (p < a.npts) {
+                const int64_t g = a.reverse ? (a.npts - 1 - p) : p;
+                double v = tile[row][col];
+                if (a.final_pass) {
+                    if (g < a.taper_len) v = v * a.tl[g];
+                    else if (g >= a.npts - a.taper_len) v = v * a.tr[g - (a.npts - a.taper_len)];
                 }
+                out[g] = v;
             }
-            __syncthreads();
         }
-    }
-    if (PHASE == 1 && chunk < a.nchunks) {
-        double* st = a.cstate + ((int64_t)chunk * a.nseries + q) * (2 * S);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            st[2 * s] = s1[s];
-            st[2 * s + 1] = s2[s];
-        }
-    }
-}
-
-// phase 2: carry the state across chunks, one lane per series.
-template <int S>
-__global__ void filter_carry_kernel(double* cstate, const double* M, int nseries, int nchans,
-                                    int64_t nchunks) {
-    constexpr int D = 2 * S;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nseries) return;
-    const int band = q / nchans;
-    double m[D][D];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) m[i][j] = M[((int64_t)band * D + i) * D + j];
-    double s[D], e[D], en[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) { s[i] = 0.0; e[i] = cstate[(int64_t)q * D + i]; }
-    for (int64_t c = 0; c < nchunks; ++c) {
-        double* cur = cstate + ((int64_t)c * nseries + q) * D;
-        if (c + 1 < nchunks) {
-            const double* nx = cstate + ((int64_t)(c + 1) * nseries + q) * D;
-#pragma unroll
-            for (int i = 0; i < D; ++i) en[i] = nx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) cur[i] = s[i];
-        double sn[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            double acc = e[i];
-#pragma unroll
-            for (int j = 0; j < D; ++j) acc += m[i][j] * s[j];
-            sn[i] = acc;
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) { s[i] = sn[i]; e[i] = en[i]; }
+        __syncthreads();
     }
 }
 
 template <int S>
-hipError_t run_pass(nbls_handle* h, const FilterArgs& base) {
-    dim3 grid((unsigned)((h->nchunks + 63) / 64), (unsigned)base.nseries);
-    hipLaunchKernelGGL((filter_chunk_kernel<S, 1>), grid, dim3(64), 0, h->stream, base);
-    hipLaunchKernelGGL((filter_carry_kernel<S>), dim3((base.nseries + 63) / 64), dim3(64), 0,
-                       h->stream, base.cstate, h->d_M, base.nseries, base.nchans, h->nchunks);
-    hipLaunchKernelGGL((filter_chunk_kernel<S, 3>), grid, dim3(64), 0, h->stream, base);
+hipError_t run_pass(nbls_handle* h, const FilterArgs& a) {
+    hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nseries),
+                       dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nseries + 63) / 64, a.ngroups), dim3(64), 0,
+                       h->stream, a);
+    hipLaunchKernelGGL((filter_carry_groups_kernel<S>), dim3((a.nseries + 63) / 64), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((filter_apply_kernel<S>), dim3((unsigned)((h->nchunks + 63) / 64), (unsigned)a.nseries),
+                       dim3(64), 0, h->stream, a);
     return hipGetLastError();
 }
 
@@ -194,8 +276,13 @@ hipError_t run_filter(nbls_handle* h) {
     a.nseries = h->nbands * h->nchans;
     a.npts = h->npts;
     a.nchunks = h->nchunks;
+    a.ngroups = (int)((h->nchunks + G - 1) / G);
     a.sos = h->d_sos;
+    a.fw = h->d_fw;
+    a.mpow = h->d_M;
     a.cstate = h->d_cstate;
+    a.gend = h->d_gend;
+    a.gin = h->d_gin;
     a.tl = h->d_tl;
     a.tr = h->d_tr;
     a.taper_len = h->taper_len;
@@ -217,8 +304,6 @@ hipError_t run_filter(nbls_handle* h) {
     return run_pass<S>(h, a);
 }
 
-}  // namespace
-
 // nsections == 0: the trace is already filtered; copy it (and apply the taper, if any).
 __global__ void copy_taper_kernel(const double* in, double* out, int64_t stride, int64_t npts, int nchans,
                                   const double* tl, const double* tr, int taper_len) {
@@ -230,6 +315,8 @@ __global__ void copy_taper_kernel(const double* in, double* out, int64_t stride,
     else if (g >= npts - taper_len) v = v * tr[g - (npts - taper_len)];
     out[ch * stride + g] = v;
 }
+
+}  // namespace
 
 hipError_t nbls_launch_filter(nbls_handle* h) {
     if (h->nsections == 0) {

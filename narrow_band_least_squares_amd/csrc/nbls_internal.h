@@ -9,6 +9,7 @@
 #define NBLS_MAX_SECTIONS 8
 #define NBLS_FILTER_CHUNK 512      // samples per scan chunk (one lane each)
 #define NBLS_FILTER_TILE 32        // samples per LDS tile row
+#define NBLS_FILTER_GROUP 64       // chunks per carry group
 #define NBLS_MAX_PAIRS 512
 #define NBLS_MAX_STARTS 1024
 #define NBLS_MAX_CAND 16
@@ -39,7 +40,11 @@ struct nbls_handle {
     int maxW = 0;
     int64_t nchunks = 0;
     double* d_sos = nullptr;       // [B][S][6]
-    double* d_M = nullptr;         // [B][D][D] chunk transition (D = 2S)
+    double* d_M = nullptr;         // [B][G+1][D][D] powers M^0..M^G of the chunk transition (D = 2S)
+    double* d_fw = nullptr;        // [B][C][D] zero-state end-state weights
+    double* d_gend = nullptr;      // [ngroups][B*N][D]
+    double* d_gin = nullptr;       // [ngroups][B*N][D]
+    size_t cap_gend = 0, cap_gin = 0;
     double* d_tl = nullptr;        // [taper_len]
     double* d_tr = nullptr;        // [taper_len]
     int32_t* d_W = nullptr;        // [B]
