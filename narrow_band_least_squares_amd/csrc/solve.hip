@@ -524,24 +524,38 @@ __device__ inline double keep_if(double v, unsigned int bit) {
     return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & m));
 }
 
-// stable rank of a[K] among a[0..PT): #{j<K: a_j <= a_K} + #{j>K: a_j < a_K}; compile-time indices
-// only (index_sequence fold), so the array stays in registers.
+// Stable ranks of a[0..PT) with ONE compare per unordered pair: for j < k let c = (a_j <= a_k)
+// (ties: lower index first).  Then rank_k = #{j<k: c_jk} + #{m>k: !c_km} = U_k + (PT-1-k) - L_k with
+// U_k = sum_{j<k} c_jk and L_k = sum_{m>k} c_km.  Compile-time indices only (index_sequence folds),
+// so a[], U[], L[] stay in registers.
 template <int PT, int K, int... J>
-__device__ inline int rank_of(const double (&a)[PT], std::integer_sequence<int, J...>) {
-    return (0 + ... + (J < K ? ((a[J] <= a[K]) ? 1 : 0) : (J > K ? ((a[J] < a[K]) ? 1 : 0) : 0)));
+__device__ inline void rank_pairs_k(const double (&a)[PT], int (&U)[PT], int (&L)[PT],
+                                    std::integer_sequence<int, J...>) {
+    auto one = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < K) {
+            const int c = (a[j] <= a[K]) ? 1 : 0;
+            U[K] += c;
+            L[j] += c;
+        }
+    };
+    (one(std::integral_constant<int, J>{}), ...);
 }
 
 template <int PT, int... K>
 __device__ inline void find_threshold(const double (&a)[PT], int h, double& T, int& kstar,
                                       std::integer_sequence<int, K...>) {
-    auto one = [&](auto kc) {
+    int U[PT], L[PT];
+    ((U[K] = 0, L[K] = 0), ...);
+    (rank_pairs_k<PT, K>(a, U, L, std::make_integer_sequence<int, PT>{}), ...);
+    auto pick = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const int r = rank_of<PT, k>(a, std::make_integer_sequence<int, PT>{});
+        const int r = U[k] + (PT - 1 - k) - L[k];
         const bool hit = (r == h - 1) & (a[k] == a[k]);
         T = hit ? a[k] : T;
         kstar = hit ? k : kstar;
     };
-    (one(std::integral_constant<int, K>{}), ...);
+    (pick(std::integral_constant<int, K>{}), ...);
 }
 
 template <int PT, int... K>
