@@ -574,11 +574,12 @@ static bool boff_ok(const int* o, int upto, int NP, int S) {
     return true;
 }
 
-static bool boff_dfs(int* o, int jj, int NP, int S) {
+static bool boff_dfs(int* o, int jj, int NP, int S, long* budget) {
     if (jj == NP) return true;
-    for (int v = (jj == 0 ? 0 : 0); v < (jj == 0 ? 1 : 16); ++v) {
+    for (int v = 0; v < (jj == 0 ? 1 : 16); ++v) {
+        if (--(*budget) < 0) return false;            // bounded search: give up, the caller falls back
         o[jj] = v;
-        if (boff_ok(o, jj, NP, S) && boff_dfs(o, jj + 1, NP, S)) return true;
+        if (boff_ok(o, jj, NP, S) && boff_dfs(o, jj + 1, NP, S, budget)) return true;
     }
     return false;
 }
@@ -623,10 +624,19 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.cmax = h->d_cmax;
     { const char* e = getenv("NBLS_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     {
-        int o[16] = {0};
-        if (!boff_dfs(o, 0, N - 1, a.S))
-            for (int q = 0; q < 16; ++q) o[q] = q;
-        for (int q = 0; q < 16; ++q) a.boff[q] = (int8_t)o[q];
+        // solved once per array size (cached); a failed/over-budget search falls back to the linear
+        // skew o[jj] = jj, which is correct and at most 2-way conflicted
+        static int cache_n = -1;
+        static int cache_o[16];
+        if (cache_n != N) {
+            int o[16] = {0};
+            long budget = 200000;
+            if (!boff_dfs(o, 0, N - 1, a.S, &budget))
+                for (int q = 0; q < 16; ++q) o[q] = q;
+            for (int q = 0; q < 16; ++q) cache_o[q] = o[q];
+            cache_n = N;
+        }
+        for (int q = 0; q < 16; ++q) a.boff[q] = (int8_t)cache_o[q];
     }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

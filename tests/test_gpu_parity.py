@@ -227,6 +227,28 @@ def test_kernel_variants_agree(monkeypatch):
         np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_gen, k))
 
 
+@pytest.mark.parametrize('nchans,winlen', [(3, 20.0), (4, 12.5), (5, 30.0), (7, 9.0), (9, 25.0), (12, 15.0), (16, 40.0)])
+def test_correlators_agree_for_any_array_size(nchans, winlen):
+    """Tile geometry depends on the element count (lag blocks per tile, partner skew, idle columns):
+    the int8-screening and f64-MFMA correlators must pick the lags of the plain VALU kernel for every
+    array size they accept, including window lengths that are not multiples of the tile steps."""
+    rij = synthetic.array_geometry(nchans, 1.0, seed=100 + nchans)
+    data = synthetic.plane_wave(rij, 6000, 40.0, 0.2, 8.0, seed=7 + nchans)
+    kw = dict(want_lag=True, want_cmax=True)
+    edges = [(0.3, 2.0), (2.0, 6.0)]
+    ref = engine.process(data, 40.0, 0.0, rij, edges, [winlen, winlen], 0.5, 1.0, 'cheby1', 2, 0.01, xcorr_impl=1, **kw)
+    for impl in (2, 3):
+        try:
+            got = engine.process(data, 40.0, 0.0, rij, edges, [winlen, winlen], 0.5, 1.0, 'cheby1', 2, 0.01,
+                                 xcorr_impl=impl, **kw)
+        except _hip.NblsError:
+            assert impl == 2 and nchans * winlen * 40.0 * 8 > 150e3     # window set too large for LDS
+            continue
+        np.testing.assert_array_equal(got.lag, ref.lag, err_msg='impl %d' % impl)
+        np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
+        np.testing.assert_array_equal(got.baz, ref.baz)
+
+
 def test_zero_channel_nan_semantics(oracle):
     """An all-zero element: its pairs give 0/0 -> NaN maxima, argmax 0 (lag W-1), nanmedian skips them."""
     c = _cfg('cfg1', 0.25)
