@@ -70,6 +70,13 @@ class BandBatch:
         self.__dict__.update(kw)
 
 
+def max_bands_per_pass(nchans, npts):
+    """Bands whose filtered traces fit the HBM budget of one pass (NBLS_MAX_FILTERED_GB, default 160 of
+    the 288 GB): each band keeps an (N, npts) float64 copy resident for the correlation stage."""
+    budget = float(os.environ.get('NBLS_MAX_FILTERED_GB', '160')) * 2.0 ** 30
+    return max(1, int(budget // (8.0 * nchans * (npts + 64))))
+
+
 def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
             filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
             want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
@@ -77,8 +84,27 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     """Run the hot path for a list of bands on one GPU.
 
     data (N, npts) raw traces; band_edges [(fmin, fmax), ...]; winlens [seconds per band].
-    prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band."""
+    prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
+    More bands than fit in HBM at once are processed in consecutive passes."""
     nchans, npts = data.shape
+    cap = max_bands_per_pass(nchans, npts)
+    if len(band_edges) > cap and not prefiltered:
+        if vector_len is None:
+            vector_len = max(1, max(planner.window_plan(npts, fs, wl, winover)[2] for wl in winlens))
+        parts = []
+        for b0 in range(0, len(band_edges), cap):
+            parts.append(process(data, fs, t0_datenum, rij, band_edges[b0:b0 + cap], winlens[b0:b0 + cap], winover,
+                                 alpha, filter_type, filter_order, filter_ripple, vector_len, device, xcorr_impl,
+                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0))
+        first = parts[0]
+
+        def cat(name):
+            vals = [getattr(p, name) for p in parts]
+            return None if vals[0] is None else np.concatenate(vals, axis=0)
+        return BandBatch(vel=cat('vel'), baz=cat('baz'), mdccm=cat('mdccm'), sigma_tau=cat('sigma_tau'),
+                         nwin=cat('nwin'), t=cat('t'), weights=cat('weights'), lag=cat('lag'), cmax=cat('cmax'),
+                         z=cat('z'), sos=[s for p in parts for s in p.sos], W=cat('W'), inc=cat('inc'),
+                         pair_idx=first.pair_idx, xij=first.xij, nchans=nchans, alpha=alpha, handle=first.handle)
     check_elements(nchans, alpha)
     nb = len(band_edges)
     h = handle if handle is not None else get_handle(device)

@@ -6,6 +6,7 @@ summarised in SURVEY.md §3.3).
 import numpy as np
 
 from . import engine
+from .uncertainty import confidence_intervals
 from .helpers import get_rij
 
 
@@ -17,8 +18,8 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
     Returns ``(vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz)``:
     trace velocity km/s, back-azimuth degrees in [0, 360), window-centre times as matplotlib
     date numbers, median cross-correlation maximum, dropped-element dictionary (``{}`` for
-    OLS), sigma_tau seconds, and the two confidence-interval vectors (NaN: not yet computed on
-    this path).  ``rij`` (2, N) km overrides the lat/lon geometry."""
+    OLS), sigma_tau seconds, and the 90 % confidence half-widths of trace velocity (km/s) and
+    back-azimuth (degrees; NaN where the direction is undetermined).  ``rij`` (2, N) km overrides the lat/lon geometry."""
     data, fs, t0 = engine.stream_to_array(st)
     nchans = data.shape[0]
     engine.check_elements(nchans, alpha)
@@ -30,7 +31,7 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
         import warnings
         warnings.warn('plot_array_coordinates is not supported on the HIP path; ignored.')
     res = engine.process(data, fs, t0, rij, [(None, None)], [window_length], window_overlap, alpha,
-                         prefiltered=True)
+                         prefiltered=True, want_z=True)
     n = int(res.nwin[0])
     vel = res.vel[0, :n].copy()
     baz = res.baz[0, :n].copy()
@@ -41,5 +42,5 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
         stdict = {}
     else:
         stdict = engine.stdict_from_weights(res.weights[0], n, t, res.pair_idx, nchans)
-    nanv = np.full(n, np.nan)
-    return vel, baz, t, mdccm, stdict, sigma_tau, nanv, nanv.copy()
+    conf_int_vel, conf_int_baz = confidence_intervals(res.xij, res.z[0, :n], sigma_tau)
+    return vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz

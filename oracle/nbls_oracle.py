@@ -688,12 +688,48 @@ def stdict_from_weights(weights, idx_pair, t, nchans):
     return stdict
 
 
+def confidence_intervals(xij, z, sigma_tau, nphi=400000):
+    """Szuberla & Olson (2004) 90 % confidence intervals [R: lts_array solve()/rthEllipse], restated from
+    the geometric definition and evaluated by brute force: the confidence ellipse (semi-axes
+    sqrt(chi2_0.90,2) sigma_tau / sqrt(eig(X^T X)) along the eigenvectors, centred on z) is sampled
+    densely; conf_int_vel = half the spread of 1/|s|, conf_int_baz = half the angle it subtends at the
+    origin (NaN if the origin is inside).  z: (2, nits)."""
+    from scipy.stats import chi2
+    nits = z.shape[1]
+    civ = np.full(nits, np.nan)
+    cib = np.full(nits, np.nan)
+    evals, evecs = np.linalg.eigh(xij.T @ xij)
+    ang = np.arccos(evecs[0, 0])
+    R = np.array([[np.cos(ang), np.sin(ang)], [-np.sin(ang), np.cos(ang)]])
+    c2 = chi2.ppf(0.90, 2)
+    phi = np.linspace(0, 2 * np.pi, nphi, endpoint=False)
+    for jj in range(nits):
+        if not (np.isfinite(z[0, jj]) and np.isfinite(z[1, jj]) and np.isfinite(sigma_tau[jj])):
+            continue
+        a = np.sqrt(c2) * sigma_tau[jj] / np.sqrt(evals[0])
+        b = np.sqrt(c2) * sigma_tau[jj] / np.sqrt(evals[1])
+        so = R @ z[:, jj]
+        if a == 0 and b == 0:
+            civ[jj] = 0.0
+            cib[jj] = 0.0
+            continue
+        pts = np.stack((so[0] + a * np.cos(phi), so[1] + b * np.sin(phi)), axis=1) @ R
+        r = np.hypot(pts[:, 0], pts[:, 1])
+        civ[jj] = 0.5 * abs(1.0 / r.min() - 1.0 / r.max())
+        if (so[0] / a) ** 2 + (so[1] / b) ** 2 <= 1.0:
+            continue                                   # origin inside the ellipse: direction undetermined
+        cdir = z[:, jj] / np.hypot(*z[:, jj])
+        rel = np.arctan2(cdir[0] * pts[:, 1] - cdir[1] * pts[:, 0], cdir[0] * pts[:, 0] + cdir[1] * pts[:, 1])
+        cib[jj] = 0.5 * np.degrees(rel.max() - rel.min())
+    return civ, cib
+
+
 def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
-          plot_array_coordinates=False, rij=None, return_internals=False):
+          plot_array_coordinates=False, rij=None, return_internals=False, ci_samples=20000):
     """lts_array.ltsva [R] -> (vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz).
 
-    conf_int_* are NaN placeholders here ("next" row).
-    ``rij`` (2,N) km overrides the lat/lon geometry (synthetic arrays)."""
+    ``rij`` (2,N) km overrides the lat/lon geometry (synthetic arrays); ``ci_samples`` is the boundary
+    sampling of the brute-force confidence-interval evaluation."""
     nchans = len(st)
     if nchans < 3:
         raise RuntimeError('ltsva needs at least 3 array elements.')
@@ -728,8 +764,8 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
         z, weights, sigma_tau = lts_post_process(tau, xij, zraw, alpha)
         vel, baz = vel_baz(z)
         stdict = stdict_from_weights(weights, idx_pair, t, nchans)
-    nanv = np.full(nits, np.nan)
-    out = (vel, baz, t, mdccm, stdict, sigma_tau, nanv.copy(), nanv.copy())
+    civ, cib = confidence_intervals(xij, z, sigma_tau, nphi=ci_samples)
+    out = (vel, baz, t, mdccm, stdict, sigma_tau, civ, cib)
     if return_internals:
         return out, dict(tau=tau, cmax=cmax, z=z, weights=weights, W=W, inc=inc,
                          intervals=intervals, xij=xij, idx_pair=idx_pair)

@@ -139,6 +139,9 @@ def test_ltsva_parity(oracle, alpha):
     for k in stdict:
         np.testing.assert_array_equal(stdict[k], out_o[4][k])
     assert len(cv) == len(vel) and len(cb) == len(vel)
+    np.testing.assert_allclose(cv, out_o[6], rtol=1e-5, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(cb, out_o[7], rtol=1e-5, atol=1e-9, equal_nan=True)
+    assert np.isfinite(cv).all()
 
 
 def test_ltsva_eight_elements_lts(oracle):
@@ -247,6 +250,20 @@ def test_correlators_agree_for_any_array_size(nchans, winlen):
         np.testing.assert_array_equal(got.lag, ref.lag, err_msg='impl %d' % impl)
         np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
         np.testing.assert_array_equal(got.baz, ref.baz)
+
+
+def test_band_passes_when_hbm_budget_is_small(monkeypatch):
+    """More bands than the filtered-trace budget allows are run in consecutive passes: same rows."""
+    c = _cfg('cfg1', 0.3)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    edges = [(c['freqlist'][i], c['freqlist'][i + 1]) for i in range(c['NBANDS'])]
+    full = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], 0.5, 1.0, 'butter', 2, 0.01)
+    monkeypatch.setenv('NBLS_MAX_FILTERED_GB', str(3.5 * 8 * data.size / 2.0 ** 30))     # three bands per pass
+    assert engine.max_bands_per_pass(*data.shape) == 3
+    split = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], 0.5, 1.0, 'butter', 2, 0.01)
+    for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 't', 'nwin'):
+        np.testing.assert_array_equal(getattr(split, k), getattr(full, k))
+    assert len(split.sos) == len(edges)
 
 
 def test_zero_channel_nan_semantics(oracle):

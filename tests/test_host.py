@@ -137,3 +137,27 @@ def test_band_sharded_path_world_size_2_gloo(gold):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=2' in r.stdout
+
+
+def test_confidence_intervals_against_brute_force(oracle):
+    """Product (closed-form tangents + Newton-refined radial extrema) vs the oracle's dense sampling of
+    the Szuberla & Olson confidence ellipse; origin-inside and exact-fit cases included."""
+    from narrow_band_least_squares_amd.uncertainty import confidence_intervals
+    rng = np.random.default_rng(12)
+    xij, _ = oracle.co_array(rng.uniform(-1, 1, size=(2, 7)))
+    z = rng.standard_normal((2, 12)) * 2.5
+    sig = np.abs(rng.standard_normal(12)) * 0.05
+    sig[3] = 0.0                      # exact fit
+    sig[5] = 50.0                     # huge ellipse: the origin is inside
+    z[:, 7] = np.nan
+    civ, cib = confidence_intervals(xij, z.T, sig)
+    ov, ob = oracle.confidence_intervals(xij, z, sig)
+    np.testing.assert_allclose(civ, ov, rtol=1e-7, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(cib, ob, rtol=1e-7, atol=1e-9, equal_nan=True)
+    assert civ[3] == 0.0 and cib[3] == 0.0 and np.isnan(cib[5]) and np.isfinite(civ[5])
+    assert np.isnan(civ[7]) and np.isnan(cib[7])
+    # a tight ellipse far from the origin: half-widths follow the small-angle formulas
+    zz = np.array([[3.0], [0.0]])
+    ev = np.linalg.eigvalsh(xij.T @ xij)
+    cv, cb = confidence_intervals(xij, zz.T, np.array([1e-6]))
+    assert cb[0] < 1e-3 and cv[0] < 1e-6
