@@ -135,6 +135,9 @@ int nbls_create(int device_id, nbls_handle** out) {
         delete h;
         return fail(nullptr, NBLS_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
     }
+    (void)hipStreamCreate(&h->stream2);
+    // two-stream pipeline: measured no gain on MI355X (both kernels fill the chip), off by default
+    { const char* e = getenv("NBLS_OVERLAP"); h->overlap = e ? atoi(e) != 0 : false; }
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     *out = h;
     return NBLS_OK;
@@ -151,6 +154,8 @@ void nbls_destroy(nbls_handle* h) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -376,9 +381,11 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    h->solve_done = false;
+    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && h->overlap;
     if (stage_mask & 2) HIPCHK(h, nbls_launch_xcorr(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    if (stage_mask & 4) HIPCHK(h, nbls_launch_solve(h));
+    if ((stage_mask & 4) && !h->solve_done) HIPCHK(h, nbls_launch_solve(h));
     if (h->prof) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_valid = true; }
     return NBLS_OK;
 }

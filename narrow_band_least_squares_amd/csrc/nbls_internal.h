@@ -17,6 +17,11 @@
 struct nbls_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
+    std::vector<hipEvent_t> pev;    // pipeline hand-off events
+    bool fuse_solve = false;        // set by nbls_execute_stages when correlation + solve run pipelined
+    bool solve_done = false;
+    bool overlap = true;            // NBLS_OVERLAP=0 disables the two-stream pipeline (profiling)
     std::string err;
 
     // ---- trace (HBM resident) ----
@@ -96,6 +101,7 @@ struct nbls_handle {
 hipError_t nbls_launch_filter(nbls_handle* h);
 hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
+hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
 bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds);
 hipError_t nbls_launch_xcorr_screen(nbls_handle* h);

@@ -21,6 +21,7 @@
 // over the subset in ascending k.  With identical lags the LTS decisions are then identical.
 #include "nbls_internal.h"
 #include <utility>
+#include <cstdlib>
 
 namespace {
 
@@ -52,6 +53,7 @@ struct SArgs {
     double quantile;
     double zero_scale;
     int use_absr;
+    int u0;                // first unit of this launch (unit batches of the pipelined path)
 };
 
 __device__ inline double dnan() { return __builtin_nan(""); }
@@ -89,8 +91,8 @@ __device__ double nanmedian_serial(const double* v, int P) {
 // OLS: one lane per unit.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void solve_ols_kernel(SArgs a, int nunits) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nunits) return;
+    const int u = a.u0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.u0 + nunits) return;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band];
     const int P = a.npairs;
@@ -243,7 +245,7 @@ template <bool ABSR>
 __global__ __launch_bounds__(LT) void solve_lts_kernel(SArgs a, int nunits) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
-    const int u = blockIdx.x;
+    const int u = a.u0 + blockIdx.x;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band];
     const int P = a.npairs;
@@ -667,8 +669,8 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int u = blockIdx.x * 4 + wv;
-    if (u >= nunits) return;
+    const int u = a.u0 + blockIdx.x * 4 + wv;
+    if (u >= a.u0 + nunits) return;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band];
     constexpr int P = PT;
@@ -695,8 +697,10 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     double* z1S = z0S + S;
     double* cres = z1S + S;       // [NBLS_MAX_CAND][3]
     int* cand = (int*)(cres + 3 * NBLS_MAX_CAND);  // [NBLS_MAX_CAND]
-    uint8_t* alive = (uint8_t*)(cand + NBLS_MAX_CAND);   // [S]
-    uint8_t* wsh = alive + S;                      // [P]
+    uint8_t* wsh = (uint8_t*)(cand + NBLS_MAX_CAND);     // [P]
+    // entry state (objS/z0S double as h-subset mask / previous objective while an entry is live)
+    uint8_t* stt = wsh + P;                        // [S] 0 dead, 1 live, 2 finished, 3 knocked out, 4 merged
+    unsigned short* act = (unsigned short*)(stt + S + ((S + P) & 1));   // [S] compact list of live entries
 
     if (lane < P) {
         const int k = lane;
@@ -736,7 +740,13 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     }
     WSYNC();
 
-    // ---- elemental starts, 64 per round ----
+    // ---- elemental starts: exact fit -> h-subset; starts that land on the SAME h-subset continue
+    //      identically from here on (a C-step depends on the subset only), so only the first of each
+    //      group is carried through the C-steps: typically 378 starts -> ~140 distinct subsets after the
+    //      initial fit and a few dozen after the first C-step.  The merged starts would have finished
+    //      with the same (objective, z) and be knocked out as duplicates by the candidate peel anyway.
+    unsigned long long* maskS = (unsigned long long*)objS;      // live entry: current h-subset
+    double* prevS = z0S;                                        // live entry: previous objective
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int s = s0 + lane;
         if (s < S) {
@@ -746,29 +756,95 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
                 const int idx = a.starts[4 * s + q];
                 if (idx >= 0) sm_ |= 1ull << idx;
             }
-            double z0, z1, obj;
+            double z0, z1;
             fit_reg<PT>(txx, txy, tyy, tbx, tby, sm_, &z0, &z1);
-            RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
-            bool active = sel.ok;
-            double prev = 0.0;
-            obj = active ? __builtin_inf() : dnan();
-            for (int kk = 0; kk < a.csteps; ++kk) {
-                if (!active) break;
-                double n0, n1;
-                fit_reg<PT>(txx, txy, tyy, tbx, tby, sel.mask, &n0, &n1);
-                sel = select_reg<PT>(y, X0, X1, h, n0, n1);
-                z0 = n0;
-                z1 = n1;
-                if (!sel.ok) { obj = dnan(); active = false; break; }
-                obj = sel.obj;
-                if (kk >= 1 && obj == prev) break;
-                prev = obj;
-            }
-            objS[s] = obj;
-            z0S[s] = z0;
-            z1S[s] = z1;
-            alive[s] = (obj == obj) && obj < __builtin_inf();
+            const RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
+            maskS[s] = sel.mask;
+            prevS[s] = 0.0;
+            stt[s] = sel.ok ? 1 : 0;
+            act[s] = (unsigned short)s;
         }
+    }
+    WSYNC();
+    int nact = S;
+    for (int kk = 0; kk <= a.csteps; ++kk) {
+        // -- rebuild the live list: drop dead/final entries and entries whose subset an earlier live
+        //    entry already has (the list is ordered by start index, so the first of a group survives)
+        if (kk <= 1) {
+            // duplicates are found with a one-probe hash table of start indices in LDS (z1S is free until
+            // the first entry finishes, which cannot happen before the second C-step): slot = min index
+            // of the entries hashing there; an entry is dropped only if the slot's entry has the SAME
+            // subset, so a hash collision merely leaves a mergeable entry in the list (harmless)
+            unsigned int* tab = (unsigned int*)z1S;
+            int hbits = 4;
+            while ((2 << hbits) * 4 <= S * 8 && hbits < 10) ++hbits;      // table bytes <= z1S bytes
+            const int HS = 1 << hbits;
+            for (int q = lane; q < HS; q += 64) tab[q] = 0xffffffffu;
+            WSYNC();
+            for (int p0 = 0; p0 < nact; p0 += 64) {
+                const int pos = p0 + lane;
+                if (pos < nact) {
+                    const int id = act[pos];
+                    if (stt[id] == 1) {
+                        const unsigned long long mk = maskS[id];
+                        const unsigned int hs = ((unsigned int)(mk ^ (mk >> 29)) * 0x9E3779B1u) >> (32 - hbits);
+                        atomicMin(&tab[hs], (unsigned int)id);
+                    }
+                }
+            }
+            WSYNC();
+            for (int p0 = 0; p0 < nact; p0 += 64) {
+                const int pos = p0 + lane;
+                if (pos < nact) {
+                    const int id = act[pos];
+                    if (stt[id] == 1) {
+                        const unsigned long long mk = maskS[id];
+                        const unsigned int hs = ((unsigned int)(mk ^ (mk >> 29)) * 0x9E3779B1u) >> (32 - hbits);
+                        const unsigned int w = tab[hs];
+                        if (w != (unsigned int)id && maskS[w] == mk) stt[id] = 4;     // merged into entry w
+                    }
+                }
+            }
+            WSYNC();
+        }
+        int nn = 0;
+        for (int p0 = 0; p0 < nact; p0 += 64) {
+            const int pos = p0 + lane;
+            const int id = pos < nact ? act[pos] : 0;
+            const bool keep = pos < nact && stt[id] == 1;
+            const unsigned long long bal = __ballot(keep);
+            const int dst = nn + __popcll(bal & ((1ull << lane) - 1ull));
+            WSYNC();
+            if (keep) act[dst] = (unsigned short)id;
+            nn += __popcll(bal);
+            WSYNC();
+        }
+        nact = nn;
+        if (kk == a.csteps || nact == 0) break;
+        // -- one C-step for every live entry
+        for (int p0 = 0; p0 < nact; p0 += 64) {
+            const int pos = p0 + lane;
+            if (pos < nact) {
+                const int id = act[pos];
+                const unsigned long long mk = maskS[id];
+                const double prev = prevS[id];
+                double n0, n1;
+                fit_reg<PT>(txx, txy, tyy, tbx, tby, mk, &n0, &n1);
+                const RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, n0, n1);
+                if (!sel.ok) {
+                    stt[id] = 0;
+                } else if ((kk >= 1 && sel.obj == prev) || kk == a.csteps - 1) {
+                    objS[id] = sel.obj;          // finished: converged, or the last allowed C-step
+                    z0S[id] = n0;
+                    z1S[id] = n1;
+                    stt[id] = 2;
+                } else {
+                    maskS[id] = sel.mask;
+                    prevS[id] = sel.obj;
+                }
+            }
+        }
+        WSYNC();
     }
     WSYNC();
 
@@ -778,7 +854,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
         for (int s = lane; s < S; s += 64) {
-            if (alive[s]) {
+            if (stt[s] == 2) {
                 const double ov = objS[s];
                 if (ov < bv || (ov == bv && s < bs)) { bv = ov; bs = s; }
             }
@@ -791,7 +867,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
         if (bs == 0x7fffffff) break;      // nothing alive (wave-uniform after the butterfly)
         const double w0 = z0S[bs], w1 = z1S[bs];
         for (int s = lane; s < S; s += 64)
-            if (alive[s] && objS[s] == bv && z0S[s] == w0 && z1S[s] == w1) alive[s] = 0;
+            if (stt[s] == 2 && objS[s] == bv && z0S[s] == w0 && z1S[s] == w1) stt[s] = 3;
         if (lane == 0) cand[nc] = bs;
         ++nc;
         WSYNC();
@@ -886,21 +962,24 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
 int lts_wave_slab_doubles(int P, int S) {
     size_t b = (size_t)(13 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
     b += (size_t)NBLS_MAX_CAND * sizeof(int);
-    b += (size_t)S + P;
+    b += (size_t)P;                     // wsh
+    b += (size_t)S + 2;                 // entry state (+ alignment of the u16 list)
+    b += (size_t)S * sizeof(unsigned short);
     b = (b + 15) & ~(size_t)15;
     return (int)(b / sizeof(double));
 }
 
 template <int PT>
-hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits) {
-    const int slab = lts_wave_slab_doubles(PT, a.nstarts);
+hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
+    int slab = lts_wave_slab_doubles(PT, a.nstarts);
+    { const char* e = getenv("NBLS_LTS_PAD_KB"); if (e) slab += atoi(e) * 128; }   // occupancy experiment
     const size_t shm = (size_t)slab * 4 * sizeof(double);
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)solve_lts_wave_kernel<PT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((solve_lts_wave_kernel<PT>), dim3((nunits + 3) / 4), dim3(256), shm, h->stream, a, nunits, slab);
+    hipLaunchKernelGGL((solve_lts_wave_kernel<PT>), dim3((nunits + 3) / 4), dim3(256), shm, st, a, nunits, slab);
     return hipGetLastError();
 }
 
@@ -915,9 +994,12 @@ size_t lts_lds_bytes(int P, int S, bool absr) {
 
 }  // namespace
 
-hipError_t nbls_launch_solve(nbls_handle* h) {
-    if (h->nunits == 0) return hipSuccess;
+hipError_t nbls_launch_solve(nbls_handle* h) { return nbls_launch_solve_range(h, 0, h->nunits, h->stream); }
+
+hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st) {
+    if (nu <= 0) return hipSuccess;
     SArgs a{};
+    a.u0 = (int)u0;
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     a.npairs = h->npairs;
@@ -933,9 +1015,9 @@ hipError_t nbls_launch_solve(nbls_handle* h) {
     a.sig = h->d_sig;
     a.z = h->d_z;
     a.wts = h->d_wts;
-    const int nunits = (int)h->nunits;
+    const int nunits = (int)nu;
     if (!h->lts) {
-        hipLaunchKernelGGL(solve_ols_kernel, dim3((nunits + 255) / 256), dim3(256), 0, h->stream, a, nunits);
+        hipLaunchKernelGGL(solve_ols_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st, a, nunits);
         return hipGetLastError();
     }
     a.xs = h->d_xs;
@@ -953,11 +1035,11 @@ hipError_t nbls_launch_solve(nbls_handle* h) {
     a.zero_scale = h->ltsp.zero_scale;
     if (h->lts_impl != 1) {
         switch (h->npairs) {     // register-resident kernel for 4..8 elements (larger P spills registers)
-            case 6: return launch_fast<6>(h, a, nunits);
-            case 10: return launch_fast<10>(h, a, nunits);
-            case 15: return launch_fast<15>(h, a, nunits);
-            case 21: return launch_fast<21>(h, a, nunits);
-            case 28: return launch_fast<28>(h, a, nunits);
+            case 6: return launch_fast<6>(h, a, nunits, st);
+            case 10: return launch_fast<10>(h, a, nunits, st);
+            case 15: return launch_fast<15>(h, a, nunits, st);
+            case 21: return launch_fast<21>(h, a, nunits, st);
+            case 28: return launch_fast<28>(h, a, nunits, st);
             default: break;
         }
     }
@@ -970,11 +1052,11 @@ hipError_t nbls_launch_solve(nbls_handle* h) {
     if (absr) {
         e = hipFuncSetAttribute((const void*)solve_lts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((solve_lts_kernel<true>), dim3(nunits), dim3(LT), shm, h->stream, a, nunits);
+        hipLaunchKernelGGL((solve_lts_kernel<true>), dim3(nunits), dim3(LT), shm, st, a, nunits);
     } else {
         e = hipFuncSetAttribute((const void*)solve_lts_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((solve_lts_kernel<false>), dim3(nunits), dim3(LT), shm, h->stream, a, nunits);
+        hipLaunchKernelGGL((solve_lts_kernel<false>), dim3(nunits), dim3(LT), shm, st, a, nunits);
     }
     return hipGetLastError();
 }

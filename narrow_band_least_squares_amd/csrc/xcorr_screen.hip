@@ -670,7 +670,25 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);
+        if (h->fuse_solve) {
+            // pipeline: the solve of this batch runs on the second stream (VALU-bound) while the next
+            // batch is quantised / screened (matrix pipe + LDS) on the first
+            while ((int64_t)h->pev.size() <= launches + 1) {
+                hipEvent_t pe;
+                if (hipEventCreateWithFlags(&pe, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+                h->pev.push_back(pe);
+            }
+            (void)hipEventRecord(h->pev[launches], h->stream);
+            (void)hipStreamWaitEvent(h->stream2, h->pev[launches], 0);
+            hipError_t se = nbls_launch_solve_range(h, u0, a.nu, h->stream2);
+            if (se != hipSuccess) return se;
+        }
         ++launches;
+    }
+    if (h->fuse_solve) {       // join: everything later on `stream` sees the solves
+        (void)hipEventRecord(h->pev[launches], h->stream2);
+        (void)hipStreamWaitEvent(h->stream, h->pev[launches], 0);
+        h->solve_done = true;
     }
     if (h->prof) h->bev_used = (int)(4 * launches);
     h->tim.xcorr_launches = launches;
