@@ -154,56 +154,80 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {     // two aligned 8-b
     return (v4i){lo[0], lo[1], hi[0], hi[1]};
 }
 
-__global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
+// One workgroup = one unit x TWO sliding channels (waves 0-3 slide channel 2*cp, waves 4-7 channel
+// 2*cp+1): the partner images of all N channels are staged once for both, which halves the staging
+// traffic and the per-workgroup fixed costs per unit.
+__global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int N = a.nchans;
-    // keep the N workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so
-    // that the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
+    const int NCP = (N + 1) / 2;                     // channel pairs per unit
+    // keep the workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so that
+    // the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
     const int b = blockIdx.x;
-    const int grp = b / (8 * N), rem = b % (8 * N);
+    const int grp = b / (8 * NCP), rem = b % (8 * NCP);
     const int ul = grp * 8 + (rem & 7);
-    const int ci = rem >> 3;                         // sliding channel
+    const int cp = rem >> 3;
     if (ul >= a.nu) return;
+    const int half = wv >> 2;                        // which sliding channel of the pair
+    const int ci = 2 * cp + half;
+    const bool chan_ok = ci < N;                     // odd N: the last pair has one channel
     const int u = a.u0 + ul;
     const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
     const int W = __builtin_amdgcn_readfirstlane(a.Wb[band]);      // wave-uniform: keeps the K loop scalar
     const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
     const int NP = N - 1;
 
-    // LDS: partner images [NP][2 limbs][CSB] (partner jj skewed by boff[jj] sixteen-byte slots so that
-    // the B fragment reads are bank-conflict free), then the 16 shifted copies of the sliding channel
+    // LDS: channel images [N][2 limbs][CSB] (channel j skewed by boff[j] sixteen-byte slots so that the
+    // B-fragment reads are bank-conflict free for every sliding channel), then per sliding channel the
+    // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
     unsigned char* Bimg = lds;
-    unsigned char* Ah = Bimg + (size_t)NP * 2 * CSB;   // [8][CSA]  copies shifted by 0..7 bytes
-    unsigned char* Al = Ah + (size_t)8 * CSA;          // [8][CSA]
-    // per-partner running maximum shared by the whole workgroup (a lower bound of the final maximum,
-    // so pruning against it is safe); without it a lane that only ever sees a slowly rising tail keeps
-    // every value as a "candidate" of its own small maximum and overflows its slots
-    int* gmax = (int*)(Al + (size_t)8 * CSA);        // [16] order-preserving int image of a float
-    if (tid < 16) gmax[tid] = (int)0x80000000;
+    unsigned char* Acop = Bimg + (size_t)N * 2 * CSB;
+    int* gmax = (int*)(Acop + (size_t)2 * 16 * CSA);  // [2][16] order-preserving int image of a float
+    if (tid < 32) gmax[tid] = (int)0x80000000;
 
-    // ---- stage the partners' limbs (zero padded front and back) ----
+    // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
+    //      eight before the LDS stores so that their latencies overlap ----
     const int gB = (CSB - 256) / 16;                 // groups written per image (skew room excluded)
+    const int nitemB = 2 * N * gB;
     if (!(a.ablate & 2))
-    for (int item = tid; item < 2 * NP * gB; item += 256) {
-        const int limb = item / (NP * gB);
-        const int r2 = item % (NP * gB);
-        const int pj = r2 / gB, g = r2 % gB;
-        const int ch = pj + (pj >= ci ? 1 : 0);
-        const int m = g * 16 - PFB;                  // sample index of the first byte of this group
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m >= 0 && m < WP)
-            v = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
-        *(uint4*)(Bimg + ((size_t)pj * 2 + limb) * CSB + 16 * a.boff[pj] + g * 16) = v;
+    for (int it0 = tid; it0 < nitemB; it0 += 512 * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int item = it0 + q * 512;
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (item < nitemB) {
+                const int limb = item / (N * gB);
+                const int r2 = item % (N * gB);
+                const int ch = r2 / gB, g = r2 % gB;
+                const int m = g * 16 - PFB;          // sample index of the first byte of this group
+                if (m >= 0 && m < WP)
+                    v[q] = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int item = it0 + q * 512;
+            if (item < nitemB) {
+                const int limb = item / (N * gB);
+                const int r2 = item % (N * gB);
+                const int ch = r2 / gB, g = r2 % gB;
+                *(uint4*)(Bimg + ((size_t)ch * 2 + limb) * CSB + 16 * a.boff[ch] + g * 16) = v[q];
+            }
+        }
     }
-    // ---- 8 byte-shifted copies of the sliding channel: A_r[m] = q_i[m + r], r = 0..7.  A lane's
+    // ---- 8 byte-shifted copies of each sliding channel: A_r[m] = q_i[m + r], r = 0..7.  A lane's
     //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
     const int gA = CSA / 8;
     if (!(a.ablate & 2))
-    for (int item = tid; item < 2 * gA; item += 256) {
-        const int limb = item / gA, g = item % gA;
-        const int8_t* src = a.qbuf + (((int64_t)ul * N + ci) * 2 + limb) * WP;
+    for (int item = tid; item < 4 * gA; item += 512) {
+        const int hs = item / (2 * gA), r2 = item % (2 * gA);
+        const int limb = r2 / gA, g = r2 % gA;
+        const int chs = 2 * cp + hs;
+        if (chs >= N) continue;
+        const int8_t* src = a.qbuf + (((int64_t)ul * N + chs) * 2 + limb) * WP;
         unsigned int sdw[4] = {0, 0, 0, 0};
         if (g * 8 < WP) {
             const uint2 lo2 = *(const uint2*)(src + g * 8);
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
             const uint2 hi2 = *(const uint2*)(src + g * 8 + 8);
             sdw[2] = hi2.x; sdw[3] = hi2.y;
         }
-        unsigned char* dst = (limb ? Al : Ah) + g * 8;
+        unsigned char* dst = Acop + ((size_t)(hs * 2 + limb) * 8) * CSA + g * 8;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int rw = r >> 2, rb = r & 3;
@@ -228,22 +252,26 @@ __global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
     // ---- lane roles ----
     const int c = lane & 15, g = lane >> 4;
     const int ncol = NP * S;
-    const bool colvalid = c < ncol;
-    const int cc = colvalid ? c : 0;                 // idle columns mirror column 0 (LDS broadcast)
+    const bool colvalid = (c < ncol) && chan_ok;
+    const int cc = (c < ncol) ? c : 0;               // idle columns mirror column 0 (LDS broadcast)
     const int jj = cc % NP;
     const int s = cc / NP;
-    const int j = jj + (jj >= ci ? 1 : 0);
-    const double* mi = a.qmeta + ((int64_t)ul * N + ci) * 4;
+    const int cis = chan_ok ? ci : 0;
+    const int j = jj + (jj >= cis ? 1 : 0);
+    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * 4;
     const double* mj = a.qmeta + ((int64_t)ul * N + j) * 4;
     // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
     // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
     const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
                             ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
     const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0) * 1.0001 + 1.0e-6 * iabs);
+    const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * 8) * CSA;
+    const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
     const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
     const unsigned char* pAl = Al + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);
-    const unsigned char* pBh = Bimg + ((size_t)jj * 2) * CSB + 16 * a.boff[jj] + PFB + 16 * g - 16 * s;   // + n'
+    const unsigned char* pBh = Bimg + ((size_t)j * 2) * CSB + 16 * a.boff[j] + PFB + 16 * g - 16 * s;   // + n'
     const unsigned char* pBl = pBh + CSB;
+    int* gmaxh = gmax + 16 * half;
 
     float lmax = -__builtin_inff();
     float sv[NSLOT];
@@ -254,10 +282,10 @@ __global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
     const int step = 16 * S;
     const int ntile = (W + step - 1) / step;
     const int ngrp4 = (ntile + TB - 1) / TB;
-    // tile groups get cheaper with p (K range W - D0): deal them to the waves in snake order
-    const int nw = blockDim.x >> 6;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    for (int rnd = 0; rnd * nw < ngrp4; ++rnd) {
+    // tile groups get cheaper with p (K range W - D0): deal them to the four waves in snake order
+    const int nw = 4;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv & 3);
+    for (int rnd = 0; chan_ok && rnd * nw < ngrp4; ++rnd) {
         const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
         if (p >= ngrp4) continue;
         const int D0 = TB * p * step;
@@ -301,8 +329,8 @@ __global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
                 }
             }
             // publish this group's maximum first, then prune against the workgroup-wide running maximum
-            if (gmx > lmax) { lmax = gmx; atomicMax(&gmax[jj], f2ord(gmx)); }
-            const float gm = ord2f(gmax[jj]);
+            if (gmx > lmax) { lmax = gmx; atomicMax(&gmaxh[jj], f2ord(gmx)); }
+            const float gm = ord2f(gmaxh[jj]);
             if (gm > lmax) lmax = gm;
             const float thr = lmax - theta;
 #pragma unroll
@@ -323,43 +351,48 @@ __global__ __launch_bounds__(256) void screen_kernel(QArgs a) {
         }
     }
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
-    int* Mj = (int*)lds;                            // [16] ordered-int image of the maximum
-    int* cnt = Mj + 16;                             // [16]
-    int* klo = cnt + 16;                            // [16] interval in np.correlate index space
-    int* khi = klo + 16;                            // [16]
-    int* lst = khi + 16;                            // [16][KOUT]
-    if (tid < 16) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
+    int* Mj = (int*)lds;                            // [2][16] ordered-int image of the maximum
+    int* cnt = Mj + 32;                             // [2][16]
+    int* klo = cnt + 32;                            // [2][16] interval in np.correlate index space
+    int* khi = klo + 32;                            // [2][16]
+    int* lst = khi + 32;                            // [2][16][KOUT]
+    if (tid < 32) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
     __syncthreads();
-    if (colvalid && lmax > -__builtin_inff()) atomicMax(&Mj[jj], f2ord(lmax));
+    const int hj = 16 * half + jj;
+    if (colvalid && lmax > -__builtin_inff()) atomicMax(&Mj[hj], f2ord(lmax));
     if (colvalid && ihi >= 0) {
         const int k1 = (ci < j) ? (W - 1 + ilo) : (W - 1 - ihi);
         const int k2 = (ci < j) ? (W - 1 + ihi) : (W - 1 - ilo);
-        atomicMin(&klo[jj], k1);
-        atomicMax(&khi[jj], k2);
+        atomicMin(&klo[hj], k1);
+        atomicMax(&khi[hj], k2);
     }
     __syncthreads();
     if (colvalid) {
-        const float thr = ord2f(Mj[jj]) - theta;
+        const float thr = ord2f(Mj[hj]) - theta;
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             if (sv[q] >= thr) {
-                const int pos = atomicAdd(&cnt[jj], 1);
-                if (pos < KOUT) lst[jj * KOUT + pos] = (ci < j) ? (W - 1 + sd[q]) : (W - 1 - sd[q]);
+                const int pos = atomicAdd(&cnt[hj], 1);
+                if (pos < KOUT) lst[hj * KOUT + pos] = (ci < j) ? (W - 1 + sd[q]) : (W - 1 - sd[q]);
             }
         }
     }
     __syncthreads();
-    for (int item = tid; item < NP * CSTRIDE; item += 256) {
-        const int pj = item / CSTRIDE, e = item % CSTRIDE;
-        const int jabs = pj + (pj >= ci ? 1 : 0);
-        int32_t* out = a.cand + (((int64_t)ul * N + ci) * N + jabs) * CSTRIDE;
-        const int n = cnt[pj];
+    for (int item = tid; item < 2 * NP * CSTRIDE; item += 512) {
+        const int hs = item / (NP * CSTRIDE), r2 = item % (NP * CSTRIDE);
+        const int pj = r2 / CSTRIDE, e = r2 % CSTRIDE;
+        const int chs = 2 * cp + hs;
+        if (chs >= N) continue;
+        const int jabs = pj + (pj >= chs ? 1 : 0);
+        int32_t* out = a.cand + (((int64_t)ul * N + chs) * N + jabs) * CSTRIDE;
+        const int hq = 16 * hs + pj;
+        const int n = cnt[hq];
         int val;
         if (e == 0) val = n < KOUT ? n : KOUT;
-        else if (e == 1) val = (khi[pj] >= 0 ? 1 : 0) | (n > KOUT ? 2 : 0);
-        else if (e == 2) val = klo[pj];
-        else if (e == 3) val = khi[pj];
-        else val = (e - 4 < n && e - 4 < KOUT) ? lst[pj * KOUT + e - 4] : 0;
+        else if (e == 1) val = (khi[hq] >= 0 ? 1 : 0) | (n > KOUT ? 2 : 0);
+        else if (e == 2) val = klo[hq];
+        else if (e == 3) val = khi[hq];
+        else val = (e - 4 < n && e - 4 < KOUT) ? lst[hq * KOUT + e - 4] : 0;
         out[e] = val;
     }
 }
@@ -546,40 +579,44 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
-// Per-partner skew (in 16-byte slots, mod 16) that makes the B-fragment ds_read_b128 of every lane
-// group conflict free: two lanes of a group may share a slot only if they read the same address.
-// Lane l reads partner jj(l), slot o[jj] + g - s; depth-first search over o[] (translation fixed by
-// o[0] = 0).  Falls back to o[jj] = jj (at most 2-way conflicts) if nothing is found.
-static bool boff_ok(const int* o, int upto, int NP, int S) {
+// Per-channel skew (in 16-byte slots, mod 16) that makes the B-fragment ds_read_b128 of every lane
+// group conflict free FOR EVERY sliding channel: two lanes of a group may share a slot only if they
+// read the same address.  Lane l reads channel j(l), slot o[j] + g - s; depth-first search over o[]
+// (translation fixed by o[0] = 0).  Falls back to o[j] = j (a few 2-way conflicts) if nothing is found.
+static bool boff_ok(const int* o, int upto, int N, int S) {
     static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                       {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                       {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
                                       {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-    for (int gi = 0; gi < 4; ++gi) {
-        int slot_addr[16];
-        for (int q = 0; q < 16; ++q) slot_addr[q] = -1000000;
-        for (int q = 0; q < 16; ++q) {
-            const int l = groups[gi][q];
-            int c = l & 15;
-            const int g = l >> 4;
-            if (c >= NP * S) c = 0;
-            const int jj = c % NP, s = c / NP;
-            if (jj > upto) continue;
-            const int addr = jj * 4096 + o[jj] + g - s;           // distinct partners never alias
-            const int slot = ((o[jj] + g - s) % 16 + 16) % 16;
-            if (slot_addr[slot] == -1000000) slot_addr[slot] = addr;
-            else if (slot_addr[slot] != addr) return false;
+    const int NP = N - 1;
+    for (int ci = 0; ci < N; ++ci) {
+        for (int gi = 0; gi < 4; ++gi) {
+            int slot_addr[16];
+            for (int q = 0; q < 16; ++q) slot_addr[q] = -1000000;
+            for (int q = 0; q < 16; ++q) {
+                const int l = groups[gi][q];
+                int c = l & 15;
+                const int g = l >> 4;
+                if (c >= NP * S) c = 0;
+                const int jj = c % NP, s = c / NP;
+                const int j = jj + (jj >= ci ? 1 : 0);
+                if (j > upto) continue;
+                const int addr = j * 4096 + o[j] + g - s;             // distinct channels never alias
+                const int slot = ((o[j] + g - s) % 16 + 16) % 16;
+                if (slot_addr[slot] == -1000000) slot_addr[slot] = addr;
+                else if (slot_addr[slot] != addr) return false;
+            }
         }
     }
     return true;
 }
 
-static bool boff_dfs(int* o, int jj, int NP, int S, long* budget) {
-    if (jj == NP) return true;
-    for (int v = 0; v < (jj == 0 ? 1 : 16); ++v) {
+static bool boff_dfs(int* o, int j, int N, int S, long* budget) {
+    if (j == N) return true;
+    for (int v = 0; v < (j == 0 ? 1 : 16); ++v) {
         if (--(*budget) < 0) return false;            // bounded search: give up, the caller falls back
-        o[jj] = v;
-        if (boff_ok(o, jj, NP, S) && boff_dfs(o, jj + 1, NP, S, budget)) return true;
+        o[j] = v;
+        if (boff_ok(o, j, N, S) && boff_dfs(o, j + 1, N, S, budget)) return true;
     }
     return false;
 }
@@ -598,7 +635,7 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     csa = round_up(csa, 32);
     while (csa % 256 != 32) csa += 32;               // copy stride == 32 B (mod 256): conflict-free ds_read_b64
     *CSA = csa;
-    *lds = (size_t)2 * (N - 1) * (*CSB) + (size_t)16 * csa + 128;
+    *lds = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 128;
     return *lds <= 160 * 1024 && *lds >= 1024;
 }
 
@@ -631,7 +668,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         if (cache_n != N) {
             int o[16] = {0};
             long budget = 200000;
-            if (!boff_dfs(o, 0, N - 1, a.S, &budget))
+            if (!boff_dfs(o, 0, N, a.S, &budget))
                 for (int q = 0; q < 16; ++q) o[q] = q;
             for (int q = 0; q < 16; ++q) cache_o[q] = o[q];
             cache_n = N;
@@ -663,7 +700,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * a.WP * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * N), dim3(256), lds, h->stream, a);
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + 1) / 2)), dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vlds <= 80 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(a.nu), dim3(512), vlds, h->stream, a);
