@@ -53,7 +53,8 @@ struct QArgs {
     int u0, nu;               // unit batch
     int WP;                   // padded window bytes (multiple of 16)
     int8_t* qbuf;             // [nu][N][2][WP]
-    double* qmeta;            // [nu][N][4]  ss, L1q, smax, 0
+    double* qmeta;            // [nu][N][qms]  ss, L1q, smax, 0, then cum[k] = sum of q^2 over samples < 32k
+    int qms;                  // doubles per (unit, channel) record = 4 + WP/32 + 2
     // screen
     int S, PFB, CSB, CSA;
     int8_t boff[16];          // per-partner LDS skew in 16-byte slots (bank-conflict-free B reads)
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     const int w = u - a.unit_off[band];
     const int W = a.Wb[band];
     const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
-    double* sm = qsm + (size_t)wv * a.WP;
+    double* sm = qsm + (size_t)wv * (a.WP + a.WP / 16 + 2);
+    double* e16 = sm + a.WP;                       // [WP/16] energy of each 16-sample group
     double mx = 0.0, ss = 0.0;
     for (int n = lane; n < a.WP; n += 64) {
         const double v = n < W ? src[n] : 0.0;
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     long long l1 = 0;
     for (int g = lane; g < a.WP / 16; g += 64) {
         unsigned int ph[4] = {0, 0, 0, 0}, pl[4] = {0, 0, 0, 0};
+        long long eg = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             int q = (int)rint(sm[g * 16 + e] * scale);
@@ -109,19 +112,33 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
             const int lo = ((q + 64) & 127) - 64;
             const int hi = (q - lo) >> 7;
             l1 += q < 0 ? -q : q;
+            eg += (long long)q * q;
             ph[e >> 2] |= (unsigned int)(hi & 0xff) << (8 * (e & 3));
             pl[e >> 2] |= (unsigned int)(lo & 0xff) << (8 * (e & 3));
         }
         *(uint4*)(qh + g * 16) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         *(uint4*)(ql + g * 16) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        e16[g] = (double)eg;
     }
     for (int off = 32; off > 0; off >>= 1) l1 += __shfl_xor(l1, off, 64);
+    double* m = a.qmeta + ((int64_t)ul * N + ch) * a.qms;
     if (lane == 0) {
-        double* m = a.qmeta + ((int64_t)ul * N + ch) * 4;
         m[0] = ss;
         m[1] = (double)l1;
         m[2] = mx;
         m[3] = 0.0;
+    }
+    // cumulative energy of the quantised window at 32-sample granularity (exact integers in double):
+    // cum[k] = sum_{n < 32k} q[n]^2, k = 0..WP/32+1 — the screening kernel bounds whole lag blocks with it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ng16 = a.WP / 16;
+    for (int k = lane; k <= a.WP / 32 + 1; k += 64) {
+        double acc = 0.0;
+        const int lim = 2 * k < ng16 ? 2 * k : ng16;
+        for (int g = 0; g < lim; ++g) acc += e16[g];
+        m[4 + k] = acc;
     }
 }
 
@@ -157,7 +174,7 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {     // two aligned 8-b
 // One workgroup = one unit x TWO sliding channels (waves 0-3 slide channel 2*cp, waves 4-7 channel
 // 2*cp+1): the partner images of all N channels are staged once for both, which halves the staging
 // traffic and the per-workgroup fixed costs per unit.
-__global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
+__global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgroups per CU: <= 128 VGPRs
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -258,8 +275,8 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
     const int s = cc / NP;
     const int cis = chan_ok ? ci : 0;
     const int j = jj + (jj >= cis ? 1 : 0);
-    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * 4;
-    const double* mj = a.qmeta + ((int64_t)ul * N + j) * 4;
+    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * a.qms;
+    const double* mj = a.qmeta + ((int64_t)ul * N + j) * a.qms;
     // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
     // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
     const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
@@ -282,13 +299,68 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
     const int step = 16 * S;
     const int ntile = (W + step - 1) / step;
     const int ngrp4 = (ntile + TB - 1) / TB;
-    // tile groups get cheaper with p (K range W - D0): deal them to the four waves in snake order
-    const int nw = 4;
     const int wvu = __builtin_amdgcn_readfirstlane(wv & 3);
+    // energy tables of the two channels of this lane's column (see quantize_kernel)
+    const double* cum_i = mi + 4;
+    const double* cum_j = mj + 4;
+    const int NB = WP / 32 + 1;
+
+// consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
+// 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
+#define SCREEN_EPILOGUE(NT, ACC)                                                                          \
+    if (colvalid && !(a.ablate & 4)) {                                                                    \
+        float v[NT * 4];                                                                                  \
+        float gmx = -__builtin_inff();                                                                    \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                  \
+            _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                         \
+                const int d = D0 + t * step + 16 * s + 4 * g + reg; /* i32 C/D: row = 4*(lane>>4)+reg */  \
+                const float x = 16384.0f * (float)ACC[t][0][reg]                                          \
+                                + 128.0f * (float)(ACC[t][1][reg] + ACC[t][2][reg]) + (float)ACC[t][3][reg]; \
+                v[t * 4 + reg] = d < W ? x : -__builtin_inff();                                           \
+                gmx = fmaxf(gmx, v[t * 4 + reg]);                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        if (gmx > lmax) { lmax = gmx; atomicMax(&gmaxh[jj], f2ord(gmx)); }                                \
+        const float gm = ord2f(gmaxh[jj]);                                                                \
+        if (gm > lmax) lmax = gm;                                                                         \
+        const float thr = lmax - theta;                                                                   \
+        _Pragma("unroll") for (int e = 0; e < NT * 4; ++e) {                                              \
+            if (v[e] >= thr) {                                                                            \
+                const int d = D0 + (e >> 2) * step + 16 * s + 4 * g + (e & 3);                            \
+                bool placed = false;                                                                      \
+                _Pragma("unroll") for (int q = 0; q < NSLOT; ++q) {                                       \
+                    const bool take = !placed && sv[q] < thr; /* free or stale slot */                    \
+                    sv[q] = take ? v[e] : sv[q];                                                          \
+                    sd[q] = take ? d : sd[q];                                                             \
+                    placed = placed || take;                                                              \
+                }                                                                                         \
+                if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }                        \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+
+    // ---- tile groups, dealt to the four waves in snake order (they get cheaper with p: K range
+    //      W - D0).  A group is skipped when, for every partner, Cauchy-Schwarz on the energies of the
+    //      overlapping parts shows that none of its lags can come within theta of the running maximum:
+    //      |I[d]| <= sqrt(E_i[d..W) * E_j[0..W-d))  for all d >= D0.  The first round (smallest lags,
+    //      where the maximum usually is) establishes the maxima; far lag blocks of coherent windows are
+    //      then never computed ----
+    const int nw = 4;
     for (int rnd = 0; chan_ok && rnd * nw < ngrp4; ++rnd) {
         const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
         if (p >= ngrp4) continue;
         const int D0 = TB * p * step;
+        if (rnd > 0 && !(a.ablate & 32)) {
+            bool prunable = true;
+            if (colvalid) {
+                const int ks = D0 / 32 < NB ? D0 / 32 : NB;
+                const int kp = (W - D0 + 31) / 32 < NB ? (W - D0 + 31) / 32 : NB;
+                const double bound = sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]);
+                const float gm = ord2f(gmaxh[jj]);
+                prunable = (float)(bound * (1.0 + 1e-6) + 1.0e-6 * iabs) < gm - theta;
+            }
+            if (__all(prunable)) continue;
+        }
         v4i c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c02 = {0, 0, 0, 0}, c03 = {0, 0, 0, 0};
         v4i c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0}, c12 = {0, 0, 0, 0}, c13 = {0, 0, 0, 0};
         v4i c20 = {0, 0, 0, 0}, c21 = {0, 0, 0, 0}, c22 = {0, 0, 0, 0}, c23 = {0, 0, 0, 0};
@@ -313,43 +385,9 @@ __global__ __launch_bounds__(512) void screen_kernel(QArgs a) {
             TILE4(a3h, a3l, c30, c31, c32, c33);
         }
         const v4i acc[TB][4] = {{c00, c01, c02, c03}, {c10, c11, c12, c13}, {c20, c21, c22, c23}, {c30, c31, c32, c33}};
-        if (colvalid && !(a.ablate & 4)) {
-            // values in f32 (the int32 limb sums recombined; relative error <= 2^-22, covered by theta)
-            float v[TB * 4];
-            float gmx = -__builtin_inff();
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int d = D0 + t * step + 16 * s + 4 * g + reg;   // i32 C/D: row = 4*(lane>>4) + reg
-                    const float x = 16384.0f * (float)acc[t][0][reg]
-                                    + 128.0f * (float)(acc[t][1][reg] + acc[t][2][reg]) + (float)acc[t][3][reg];
-                    v[t * 4 + reg] = d < W ? x : -__builtin_inff();
-                    gmx = fmaxf(gmx, v[t * 4 + reg]);
-                }
-            }
-            // publish this group's maximum first, then prune against the workgroup-wide running maximum
-            if (gmx > lmax) { lmax = gmx; atomicMax(&gmaxh[jj], f2ord(gmx)); }
-            const float gm = ord2f(gmaxh[jj]);
-            if (gm > lmax) lmax = gm;
-            const float thr = lmax - theta;
-#pragma unroll
-            for (int e = 0; e < TB * 4; ++e) {
-                if (v[e] >= thr) {
-                    const int d = D0 + (e >> 2) * step + 16 * s + 4 * g + (e & 3);
-                    bool placed = false;
-#pragma unroll
-                    for (int q = 0; q < NSLOT; ++q) {
-                        const bool take = !placed && sv[q] < thr;   // free or stale slot
-                        sv[q] = take ? v[e] : sv[q];
-                        sd[q] = take ? d : sd[q];
-                        placed = placed || take;
-                    }
-                    if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }
-                }
-            }
-        }
+        SCREEN_EPILOGUE(TB, acc)
     }
+#undef SCREEN_EPILOGUE
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
     int* Mj = (int*)lds;                            // [2][16] ordered-int image of the maximum
     int* cnt = Mj + 32;                             // [2][16]
@@ -498,8 +536,8 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
             const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
             const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
             recs[q] = lane < 32 ? l1[lane] : l2[lane - 32];
-            ssA[q] = a.qmeta[((int64_t)ul * N + ci) * 4];
-            ssB[q] = a.qmeta[((int64_t)ul * N + cj) * 4];
+            ssA[q] = a.qmeta[((int64_t)ul * N + ci) * a.qms];
+            ssB[q] = a.qmeta[((int64_t)ul * N + cj) * a.qms];
         }
     }
     for (int ch = wv; ch < N; ch += nwv) {
@@ -520,8 +558,8 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
                 const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
                 const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
                 rec = lane < 32 ? l1[lane] : l2[lane - 32];
-                ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
-                ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
+                ssa = a.qmeta[((int64_t)ul * N + ci) * a.qms];
+                ssb = a.qmeta[((int64_t)ul * N + cj) * a.qms];
             }
             double best;
             int bestk;
@@ -547,8 +585,8 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
-    const double ssa = a.qmeta[((int64_t)ul * N + ci) * 4];
-    const double ssb = a.qmeta[((int64_t)ul * N + cj) * 4];
+    const double ssa = a.qmeta[((int64_t)ul * N + ci) * a.qms];
+    const double ssb = a.qmeta[((int64_t)ul * N + cj) * a.qms];
     double best;
     int bestk;
     const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
@@ -653,6 +691,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.unit_band = h->d_unit_band;
     a.qbuf = h->d_qbuf;
     a.qmeta = h->d_qmeta;
+    a.qms = 4 + a.WP / 32 + 2;
+    a.qms += a.qms & 1;
     a.cand = h->d_cand;
     a.npairs = h->npairs;
     a.pair = h->d_pair;
@@ -697,7 +737,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
         hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
-        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * a.WP * sizeof(double), h->stream, a);
+        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 16 + 2) * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + 1) / 2)), dim3(512), lds, h->stream, a);
