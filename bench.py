@@ -9,8 +9,11 @@ One process per GPU (N > 1: launched by torch.distributed.run, backend nccl = RC
 one pass of the whole hot path — filter + taper, pairwise cross-correlation / lag pick, MdCCM,
 FAST-LTS + reweighting — over every (band, window) unit of the rank's bands, with the raw trace
 already resident in HBM, plus (N > 1) the single all-gather of the result grids and the D2H copy
-of the grids.  Scaling is weak: every rank owns 48 bands (the band grid 0.1-10 Hz is refined to
-48*N bands), so per-GPU work is fixed and value = all units of all ranks / max-over-ranks time.
+of the grids.  Scaling is weak: every rank runs the same 48 bands over its OWN six-hour trace (an
+independent station-day, generator seed + rank), so per-GPU work is fixed and statistically identical,
+and value = all units of all ranks / max-over-ranks time.  (Sharding the bands of ONE call over the
+GPUs — strong scaling, what narrow_band_least_squares_parallel() does — leaves 6 bands = 4 ms of work per
+GPU at N = 8, which measures launch latency, not the path.)
 
 The JSON line carries `roofline` (dominant kernel = the cross-correlation; duration measured with
 HIP events on the library's own stream) and `cpu_baseline` (the CPU oracle, band-parallel over
@@ -29,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from narrow_band_least_squares_amd import dist, engine, planner, synthetic  # noqa: E402
-from narrow_band_least_squares_amd.helpers import get_freqlist  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (AMD datasheet; the guide lists none)
 I8_MFMA_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: int8 MFMA = 2x the bf16 dense rate (~2.5 PF) per clock
@@ -97,14 +99,13 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
-    c = synthetic.build_config(args.config, scale=args.scale)
+    c = synthetic.build_config(args.config, scale=args.scale, trace_seed=synthetic.SEED + 1 + rank)
     bands_per_gpu = c['NBANDS']
-    total_bands = bands_per_gpu * world
-    freqlist, _, _ = get_freqlist(c['fmin'], c['fmax'], c['band_type'], total_bands)
+    total_bands = bands_per_gpu
+    freqlist = c['freqlist']
     all_edges = [(freqlist[i], freqlist[i + 1]) for i in range(total_bands)]
-    my_bands = list(range(rank, total_bands, world))      # equal cost per band: round-robin
-    edges = [all_edges[b] for b in my_bands]
-    winlens = [c['WINLEN_list'][0]] * len(edges)
+    edges = all_edges
+    winlens = list(c['WINLEN_list'])
 
     data, fs, t0 = engine.stream_to_array(c['st'])
     nchans, npts = data.shape
@@ -184,12 +185,13 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cfg-3: 8-element synthetic plane wave, %d bands/GPU (%d total) log 0.1-10 Hz, '
-                                   'LTS alpha=0.5, 6 h @ 40 Hz, 30 s windows 50%% overlap, butter order 2 zero-phase'
-                                   % (bands_per_gpu, total_bands),
+            'config': {'workload': 'cfg-3: 8-element synthetic plane wave, %d log bands 0.1-10 Hz, LTS alpha=0.5, '
+                                   '6 h @ 40 Hz, 30 s windows 50%% overlap, butter order 2 zero-phase; one '
+                                   'independent 6 h trace per GPU (%d trace(s))' % (bands_per_gpu, world),
                        'units_per_gpu': units_rank, 'elements': nchans, 'pairs': P, 'window_samples': W,
                        'lts_starts': None if lts is None else int(lts['starts'].shape[0]),
-                       'parallelism': 'bands sharded over %d GPU(s), one all-gather of the grids' % world,
+                       'parallelism': '%d GPU(s), (band x window x trace) units sharded by trace, one all-gather '
+                                      'of the grids' % world,
                        'scale': args.scale},
             'stage_ms': {'filter': float(np.mean(fl)), 'xcorr': xcorr_ms, 'solve': float(np.mean(sv)),
                          'xcorr_quantize': float(np.mean(qz)), 'xcorr_screen': float(np.mean(scr)),

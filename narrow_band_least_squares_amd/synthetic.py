@@ -87,7 +87,7 @@ CONFIGS = {
 }
 
 
-def build_config(name, scale=1.0):
+def build_config(name, scale=1.0, trace_seed=SEED + 1):
     """-> dict(st, rij, lat, lon, freqlist, WINLEN_list, ...) for a named configuration.
     ``scale`` < 1 shortens the trace (for tests)."""
     from .helpers import get_freqlist, get_winlenlist
@@ -97,7 +97,7 @@ def build_config(name, scale=1.0):
     lts = c['alpha'] < 1.0
     data = plane_wave(rij, npts, c['fs'], c['fmin'], c['fmax'],
                       timing_error_s=0.25 if lts else 0.0,
-                      bad_element=c['N'] - 1 if lts else None)
+                      bad_element=c['N'] - 1 if lts else None, seed=trace_seed)
     lat, lon = latlon_from_rij(rij)
     st = make_stream(data, c['fs'], lat=lat, lon=lon)
     freqlist, nbands, fmax = get_freqlist(c['fmin'], c['fmax'], c['band_type'], c['B'])
