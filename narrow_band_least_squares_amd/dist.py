@@ -59,7 +59,7 @@ def all_gather_arrays(arr, device_index=None):
     import torch
     import torch.distributed as td
     rank, world, backend = dist_info()
-    if world == 1:
+    if backend is None:
         return [arr]
     t = torch.from_numpy(np.ascontiguousarray(arr))
     if backend == 'nccl':

@@ -137,7 +137,8 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     this is the single-GPU batched call.  Results are identical either way: no value crosses
     bands."""
     rank, world, backend = dist.dist_info()
-    if world == 1:
+    import os
+    if world == 1 and not (backend is not None and os.environ.get('NBLS_FORCE_DIST_PATH') == '1'):
         return narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS, w, h,
                                          freqlist, FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
                                          FILTER_RIPPLE, rij=rij)

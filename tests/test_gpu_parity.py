@@ -266,6 +266,51 @@ def test_band_passes_when_hbm_budget_is_small(monkeypatch):
     assert len(split.sos) == len(edges)
 
 
+def test_band_sharded_entry_point_under_rccl():
+    """narrow_band_least_squares_parallel() through torch.distributed's nccl (= RCCL) backend: one rank
+    on this box's GPU, sharded code path forced; must equal the serial call bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', '29541', os.path.join(root, 'tests', '_dist_gpu_worker.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'DIST_GPU_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('name', ['loop_ols_cheby1_adaptive', 'loop_ols_butter_linear', 'loop_lts_butter_octave',
+                                  'loop_lts_2octave'])
+def test_product_against_reference_loop_goldens(name):
+    """The GPU path against the fixtures produced by the REFERENCE's own narrow_band_least_squares() /
+    ..._parallel() loops (tests/golden/make_goldens.py; ltsva/obspy stubbed by the oracle there): shapes,
+    num_compute_list, zero padding, stdict keys (incl. the overlapping '2_octave_over' bands) and values."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'), allow_pickle=False)
+    st = synthetic.make_stream(g['data'], float(g['fs']), starttime=17884.0729166667)
+    nb = len(g['num_compute'])
+    fr = g['freq_resp']
+    w = np.zeros(len(fr))
+    out = narrow_band_least_squares(list(g['winlens']), 0.5, float(g['alpha']), st, None, None, nb, w, w,
+                                    list(g['freqlist']), str(g['band_type']), fr, str(g['ftype']), 2, 0.01,
+                                    rij=g['rij'])
+    assert out[6] == list(g['num_compute']) and out[0].shape == (nb, int(g['vector_len']))
+    for i, key in ((0, 'vel'), (1, 'baz'), (2, 'mdccm'), (5, 'sig')):
+        np.testing.assert_allclose(out[i], g[key], rtol=1e-9, atol=1e-15, err_msg=key)
+    np.testing.assert_array_equal(out[3], g['t'])
+    np.testing.assert_allclose(out[8], g['h_array'], rtol=1e-9, atol=1e-13)
+    if int(g['stdict_size']) < 0:
+        assert out[4] is None
+    else:
+        keys = [str(k) for k in g['stdict_keys']]
+        assert sorted(k for k in out[4] if k != 'size') == sorted(keys) and out[4]['size'] == int(g['stdict_size'])
+        off = 0
+        for k, n in zip(keys, g['stdict_lens']):
+            np.testing.assert_array_equal(out[4][k], g['stdict_vals'][off:off + n])
+            off += n
+
+
 def test_zero_channel_nan_semantics(oracle):
     """An all-zero element: its pairs give 0/0 -> NaN maxima, argmax 0 (lag W-1), nanmedian skips them."""
     c = _cfg('cfg1', 0.25)
