@@ -112,6 +112,13 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
               int32_t taper_len, const int32_t* winlen, const int32_t* wininc,
               int32_t vector_len, const nbls_lts_params* lts, int32_t xcorr_impl);
 
+/* Window sharding (fewer bands than GPUs, or traces too long for one GPU's time
+ * budget): restrict the NEXT plans to windows [first[b], first[b] + count[b]) of band b (count < 0 =
+ * to the end).  The filter still runs over the whole trace (zero-phase filtering is not local in time),
+ * correlation and solve only over the slice; result rows keep their global window index, rows outside
+ * the slice stay zero, so the slices of several GPUs combine by addition.  nbands <= 0 resets. */
+int nbls_set_window_ranges(nbls_handle* h, int32_t nbands, const int32_t* first, const int32_t* count);
+
 /* Launch the whole pass (filter -> xcorr/lag pick -> MdCCM + OLS|LTS) asynchronously on the
  * handle's stream; nbls_sync waits for it. */
 int nbls_execute(nbls_handle* h);

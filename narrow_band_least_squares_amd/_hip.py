@@ -15,7 +15,7 @@ EXPORTS = [
     'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
     'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
-    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats',
+    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -85,6 +85,7 @@ def load_library(path=None):
     lib.nbls_probe_mfma_f64.argtypes = [vp, dp, dp, dp]
     lib.nbls_probe_mfma_i8.argtypes = [vp, ip, ip, ip]
     lib.nbls_debug_screen_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.nbls_set_window_ranges.argtypes = [vp, C.c_int32, ip, ip]
     for name in EXPORTS:
         if name not in ('nbls_destroy', 'nbls_last_error'):
             getattr(lib, name).restype = C.c_int
@@ -200,6 +201,15 @@ class Handle:
                                      len(tl), _iptr(winlen), _iptr(wininc), int(vector_len), lp,
                                      int(xcorr_impl)))
         self.nbands, self.vector_len = nb, int(vector_len)
+
+    def set_window_ranges(self, first=None, count=None):
+        """Per-band window slices for the next plan(s); None resets to "all windows"."""
+        if first is None:
+            self._chk(self.lib.nbls_set_window_ranges(self._h, 0, None, None))
+            return
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        count = np.ascontiguousarray(count, dtype=np.int32)
+        self._chk(self.lib.nbls_set_window_ranges(self._h, len(first), _iptr(first), _iptr(count)))
 
     def execute(self, stages=7):
         self._chk(self.lib.nbls_execute_stages(self._h, int(stages)))

@@ -150,7 +150,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
                     h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -206,6 +206,21 @@ int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx
     return NBLS_OK;
 }
 
+int nbls_set_window_ranges(nbls_handle* h, int32_t nbands, const int32_t* first, const int32_t* count) {
+    if (!h) return NBLS_ERR_ARG;
+    // consumed by the NEXT nbls_plan; an existing plan keeps the ranges it was made with
+    if (nbands <= 0 || !first || !count) {       // reset: every band processes all its windows
+        h->win_first.clear();
+        h->win_count.clear();
+        return NBLS_OK;
+    }
+    for (int b = 0; b < nbands; ++b)
+        if (first[b] < 0) return fail(h, NBLS_ERR_ARG, "nbls_set_window_ranges: negative first window");
+    h->win_first.assign(first, first + nbands);
+    h->win_count.assign(count, count + nbands);
+    return NBLS_OK;
+}
+
 int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections, int32_t zero_phase,
               const double* taper_left, const double* taper_right, int32_t taper_len,
               const int32_t* winlen, const int32_t* wininc, int32_t vector_len,
@@ -239,6 +254,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     h->inc.assign(wininc, wininc + nbands);
     h->nwin.resize(nbands);
     h->unit_off.resize(nbands + 1);
+    std::vector<int32_t> woff(nbands, 0);
     int64_t U = 0;
     int maxW = 0;
     for (int b = 0; b < nbands; ++b) {
@@ -247,8 +263,16 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
             return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2..3840 samples");
         // len(arange(0, npts - W, inc))
         const int64_t span = h->npts - W;
-        const int64_t n = span > 0 ? (span + inc - 1) / inc : 0;
+        int64_t n = span > 0 ? (span + inc - 1) / inc : 0;
         if (n > vector_len) return fail(h, NBLS_ERR_ARG, "nbls_plan: vector_len smaller than a band's window count");
+        int64_t first = 0;
+        if ((int)h->win_first.size() == nbands) {          // window sharding: this handle's slice of the band
+            first = h->win_first[b] < n ? h->win_first[b] : n;
+            int64_t cnt = h->win_count[b] < 0 ? n - first : h->win_count[b];
+            if (cnt > n - first) cnt = n - first;
+            n = cnt;
+        }
+        woff[b] = (int32_t)first;
         h->nwin[b] = (int32_t)n;
         h->unit_off[b] = (int32_t)U;
         U += n;
@@ -284,6 +308,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if ((rc = alloc_copy(h, &h->d_inc, h->inc.data(), (size_t)nbands))) return rc;
     if ((rc = alloc_copy(h, &h->d_nwin, h->nwin.data(), (size_t)nbands))) return rc;
     if ((rc = alloc_copy(h, &h->d_unit_off, h->unit_off.data(), (size_t)nbands + 1))) return rc;
+    if ((rc = alloc_copy(h, &h->d_win_off, woff.data(), (size_t)nbands))) return rc;
     std::vector<int32_t> ub((size_t)U);
     for (int b = 0; b < nbands; ++b)
         for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) ub[(size_t)u] = b;

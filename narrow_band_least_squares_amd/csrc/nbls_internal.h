@@ -56,6 +56,8 @@ struct nbls_handle {
     int32_t* d_inc = nullptr;      // [B]
     int32_t* d_nwin = nullptr;     // [B]
     int32_t* d_unit_off = nullptr; // [B+1]
+    int32_t* d_win_off = nullptr;  // [B] first window processed per band
+    std::vector<int32_t> win_first, win_count;   // optional per-band window ranges (nbls_set_window_ranges)
     int32_t* d_unit_band = nullptr;// [U]
 
     // ---- work + results ----

@@ -31,6 +31,7 @@ struct SArgs {
     int npairs;
     int vector_len;
     const int32_t* unit_off;
+    const int32_t* win_off;   // [B] first window of each band's range (window sharding)
     const int32_t* unit_band;
     double fs;
     const double* xij;     // [P][2]
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void solve_ols_kernel(SArgs a, int nunits) {
     const int u = a.u0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= a.u0 + nunits) return;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int P = a.npairs;
     const int64_t o = (int64_t)band * a.vector_len + w;
     const int32_t* lag = a.lag + o * P;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(LT) void solve_lts_kernel(SArgs a, int nunits) {
     const int tid = threadIdx.x;
     const int u = a.u0 + blockIdx.x;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int P = a.npairs;
     const int S = a.nstarts;
     const int h = a.h;
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     const int u = a.u0 + blockIdx.x * 4 + wv;
     if (u >= a.u0 + nunits) return;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     constexpr int P = PT;
     const int S = a.nstarts;
     const int h = a.h;
@@ -1005,6 +1006,7 @@ hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.npairs = h->npairs;
     a.vector_len = h->vector_len;
     a.unit_off = h->d_unit_off;
+    a.win_off = h->d_win_off;
     a.unit_band = h->d_unit_band;
     a.fs = h->fs;
     a.xij = h->d_xij;

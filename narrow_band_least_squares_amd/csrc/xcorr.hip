@@ -25,6 +25,7 @@ struct XArgs {
     const int32_t* Wb;        // [B]
     const int32_t* incb;      // [B]
     const int32_t* unit_off;  // [B+1]
+    const int32_t* win_off;   // [B] first window of each band's range (window sharding)
     const int32_t* unit_band; // [U]
     int vector_len;
     int32_t* lag;             // [B][VL][P]
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
     const int u = (int)(bid / a.npairs);
     const int k = (int)(bid % a.npairs);
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
     const int N = a.nchans;
     const int u = blockIdx.x;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     const int S = a.S, CS = a.CS, PF = a.PF;
@@ -257,6 +258,7 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     a.Wb = h->d_W;
     a.incb = h->d_inc;
     a.unit_off = h->d_unit_off;
+    a.win_off = h->d_win_off;
     a.unit_band = h->d_unit_band;
     a.vector_len = h->vector_len;
     a.lag = h->d_lag;

@@ -49,6 +49,7 @@ struct QArgs {
     const int32_t* Wb;
     const int32_t* incb;
     const int32_t* unit_off;
+    const int32_t* win_off;   // [B] first window of each band's range (window sharding)
     const int32_t* unit_band;
     int u0, nu;               // unit batch
     int WP;                   // padded window bytes (multiple of 16)
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     const int ul = item / N, ch = item % N;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
     double* sm = qsm + (size_t)wv * (a.WP + a.WP / 16 + 2);
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     const int ul = blockIdx.x;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     // issue the candidate-record and norm loads of this wave's pairs first: their latency hides
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
     const int ul = item / P, k = item % P;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
@@ -688,6 +689,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.Wb = h->d_W;
     a.incb = h->d_inc;
     a.unit_off = h->d_unit_off;
+    a.win_off = h->d_win_off;
     a.unit_band = h->d_unit_band;
     a.qbuf = h->d_qbuf;
     a.qmeta = h->d_qmeta;

@@ -80,8 +80,11 @@ def max_bands_per_pass(nchans, npts):
 def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
             filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
             want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
-            upload=True):
+            upload=True, window_slice=None):
     """Run the hot path for a list of bands on one GPU.
+
+    window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
+    sharding across GPUs); rows outside the slice stay zero, ``nwin``/``t`` describe the whole band.
 
     data (N, npts) raw traces; band_edges [(fmin, fmax), ...]; winlens [seconds per band].
     prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
@@ -95,7 +98,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         for b0 in range(0, len(band_edges), cap):
             parts.append(process(data, fs, t0_datenum, rij, band_edges[b0:b0 + cap], winlens[b0:b0 + cap], winover,
                                  alpha, filter_type, filter_order, filter_ripple, vector_len, device, xcorr_impl,
-                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0))
+                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0, window_slice))
         first = parts[0]
 
         def cat(name):
@@ -140,7 +143,15 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         sos = planner.pad_sections(applied)
         tl, tr = planner.taper_ramps(npts)
     lts = planner.lts_plan(xij, alpha) if alpha < 1.0 else None
-    h.plan(sos, zero_phase, tl, tr, W, inc, vector_len, lts=lts, xcorr_impl=xcorr_impl)
+    if window_slice is not None:
+        k, n = window_slice
+        first = (nwin * k) // n
+        h.set_window_ranges(first, (nwin * (k + 1)) // n - first)
+    try:
+        h.plan(sos, zero_phase, tl, tr, W, inc, vector_len, lts=lts, xcorr_impl=xcorr_impl)
+    finally:
+        if window_slice is not None:
+            h.set_window_ranges(None)
     h.execute()
     h.sync()
     out = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_weights=lts is not None, want_z=want_z)
@@ -148,7 +159,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     for b in range(nb):
         t[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
     return BandBatch(vel=out['vel'], baz=out['baz'], mdccm=out['mdccm'], sigma_tau=out['sigma_tau'],
-                     nwin=out['nwin'].astype(int), t=t, weights=out['weights'], lag=out['lag'],
+                     nwin=nwin.astype(int), t=t, weights=out['weights'], lag=out['lag'],
                      cmax=out['cmax'], z=out['z'], sos=sos_ret, W=W, inc=inc, pair_idx=pair_idx,
                      xij=xij, nchans=nchans, alpha=alpha, handle=h)
 

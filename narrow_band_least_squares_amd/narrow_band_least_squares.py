@@ -7,6 +7,8 @@ Reference: narrow_band_least_squares.py:8-127 (serial), :134-218 (``narrow_band_
 the GPUs of a node when a ``torch.distributed`` process group is active (one process per GPU)
 and gathers the grids once at the end; without a process group it equals the serial call.
 """
+import os
+
 import numpy as np
 from scipy import signal
 
@@ -137,11 +139,14 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     this is the single-GPU batched call.  Results are identical either way: no value crosses
     bands."""
     rank, world, backend = dist.dist_info()
-    import os
     if world == 1 and not (backend is not None and os.environ.get('NBLS_FORCE_DIST_PATH') == '1'):
         return narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS, w, h,
                                          freqlist, FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
                                          FILTER_RIPPLE, rij=rij)
+    if NBANDS < world or os.environ.get('NBLS_SHARD') == 'windows':
+        return _parallel_by_windows(rank, world, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS,
+                                    freqlist, FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
+                                    FILTER_RIPPLE, rij)
     vector_len = _vector_len(WINLEN_list, WINOVER, st)
     npts = len(st[0].data)
     fs = float(st[0].stats.sampling_rate)
@@ -205,3 +210,45 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
             stdict_all = {**stdict_all, **per_band_dict[b]}
     return (vel_array, baz_array, mdccm_array, t_array, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
+
+
+def _parallel_by_windows(rank, world, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS, freqlist,
+                         FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, rij):
+    """Fewer bands than GPUs (octave bands, example.py's 8 bands on a bigger node, ...): every rank takes
+    ALL bands but only its contiguous slice of each band's windows.  The filter runs
+    over the whole trace on every rank (zero-phase filtering is not local in time; it is a few per cent of
+    the work), correlation and solve only over the slice.  Slices are disjoint and unprocessed rows are
+    zero, so the full grids are the sum of the gathered per-rank grids."""
+    vector_len = _vector_len(WINLEN_list, WINOVER, st)
+    data, fs, t0 = engine.stream_to_array(st)
+    nchans = data.shape[0]
+    if rij is None:
+        rij = get_rij(lat_list, lon_list, nchans)
+    bands = list(range(NBANDS))
+    edges = _band_edges(freqlist, FREQ_BAND_TYPE, bands)
+    res = engine.process(data, fs, t0, rij, edges, [WINLEN_list[ii] for ii in bands], WINOVER, ALPHA, FILTER_TYPE,
+                         FILTER_ORDER, FILTER_RIPPLE, vector_len=vector_len, window_slice=(rank, world))
+    F = len(freq_resp_list)
+    w_array = np.zeros((NBANDS, F), dtype=complex)
+    h_array = np.zeros((NBANDS, F), dtype=complex)
+    for n, ii in enumerate(bands):
+        ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
+        w_array[n, :], h_array[n, :] = ww, hh
+        if rank == 0:
+            _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
+    dev = engine.default_device()
+    grids = np.stack((res.vel, res.baz, res.mdccm, res.sigma_tau))
+    total = np.sum(dist.all_gather_arrays(grids, dev), axis=0)
+    num_compute_list = [int(n) for n in res.nwin]
+    if ALPHA == 1.0:
+        stdict_all = None
+        sig_tau_array = total[3]
+    else:
+        wts = np.sum(dist.all_gather_arrays(res.weights, dev), axis=0, dtype=np.uint8)
+        # rows outside every slice do not exist (beyond num_compute); inside, exactly one rank wrote 0/1
+        stdict_all = {}
+        for n, ii in enumerate(bands):
+            sd = engine.stdict_from_weights(wts[n], num_compute_list[n], res.t[n], res.pair_idx, nchans)
+            stdict_all = {**stdict_all, **_prefix_stdict(sd, ii + 1)}
+        sig_tau_array = np.zeros_like(total[3])
+    return (total[0], total[1], total[2], res.t, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)

@@ -17,7 +17,7 @@ nbls_mod = importlib.import_module('narrow_band_least_squares_amd.narrow_band_le
 
 
 def fake_process(data, fs, t0, rij, band_edges, winlens, winover, alpha, filter_type=None, filter_order=None,
-                 filter_ripple=None, vector_len=None, **kw):
+                 filter_ripple=None, vector_len=None, window_slice=None, **kw):
     nb = len(band_edges)
     nchans = data.shape[0]
     xij, pair_idx, _ = planner.co_array(rij)
@@ -36,6 +36,14 @@ def fake_process(data, fs, t0, rij, band_edges, winlens, winover, alpha, filter_
         nwin[b] = n
         vel[b, :n], baz[b, :n], t[b, :n], md[b, :n], sig[b, :n] = out[0], out[1], out[2], out[3], out[5]
         wts[b, :n] = internals['weights'].T
+        if window_slice is not None:          # keep only this rank's slice of the rows, like the device path
+            k, nsl = window_slice
+            lo, hi = (n * k) // nsl, (n * (k + 1)) // nsl
+            for arr in (vel, baz, md, sig):
+                arr[b, :lo] = 0.0
+                arr[b, hi:] = 0.0
+            wts[b, :lo] = 0
+            wts[b, hi:] = 0
     return engine.BandBatch(vel=vel, baz=baz, mdccm=md, sigma_tau=sig, nwin=nwin, t=t, weights=wts, sos=sos,
                             pair_idx=pair_idx, nchans=nchans)
 
@@ -45,6 +53,8 @@ def main():
     td.init_process_group('gloo')
     rank = td.get_rank()
     engine.process = fake_process
+    if len(sys.argv) > 2:
+        os.environ['NBLS_SHARD'] = sys.argv[2]
     gold = np.load(os.path.join(ROOT, 'tests', 'golden', sys.argv[1] + '.npz'), allow_pickle=False)
     st = oracle.make_stream(gold['data'], float(gold['fs']), starttime=17884.0729166667)
     nb = len(gold['num_compute'])

@@ -128,12 +128,13 @@ def test_shard_bands_is_a_balanced_partition():
     assert dist.dist_info()[1] == 1
 
 
-@pytest.mark.parametrize('gold', ['loop_ols_butter_linear', 'loop_lts_butter_octave'])
-def test_band_sharded_path_world_size_2_gloo(gold):
+@pytest.mark.parametrize('gold,mode', [('loop_ols_butter_linear', 'bands'), ('loop_lts_butter_octave', 'bands'),
+                                       ('loop_ols_butter_linear', 'windows'), ('loop_lts_butter_octave', 'windows')])
+def test_band_sharded_path_world_size_2_gloo(gold, mode):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', '29533',
-           os.path.join(ROOT, 'tests', '_dist_worker.py'), gold]
+           os.path.join(ROOT, 'tests', '_dist_worker.py'), gold, mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=2' in r.stdout
