@@ -166,6 +166,8 @@ int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32
 /* Developer statistic of the int8 screening correlator (last unit batch): out4 = {ordered pairs,
  * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
 int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
+/* Developer: mean s_memtime cycles of the screen kernel's phases (needs NBLS_SCREEN_STAMPS=1 at plan time). */
+int nbls_debug_screen_stamps(nbls_handle* h, double* out6);
 
 #ifdef __cplusplus
 }

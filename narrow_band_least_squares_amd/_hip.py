@@ -15,7 +15,7 @@ EXPORTS = [
     'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
     'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
-    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges',
+    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -86,6 +86,7 @@ def load_library(path=None):
     lib.nbls_probe_mfma_i8.argtypes = [vp, ip, ip, ip]
     lib.nbls_debug_screen_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.nbls_set_window_ranges.argtypes = [vp, C.c_int32, ip, ip]
+    lib.nbls_debug_screen_stamps.argtypes = [vp, dp]
     for name in EXPORTS:
         if name not in ('nbls_destroy', 'nbls_last_error'):
             getattr(lib, name).restype = C.c_int
@@ -251,6 +252,11 @@ class Handle:
         return dict(filter_ms=t.filter_ms, xcorr_ms=t.xcorr_ms, solve_ms=t.solve_ms,
                     total_ms=t.total_ms, xcorr_launches=t.xcorr_launches, quantize_ms=t.quantize_ms,
                     screen_ms=t.screen_ms, verify_ms=t.verify_ms, xcorr_impl=t.xcorr_impl)
+
+    def screen_stamps(self):
+        out = np.zeros(6)
+        self._chk(self.lib.nbls_debug_screen_stamps(self._h, _dptr(out)))
+        return dict(zip(('stage_issue', 'stage_wait', 'compute_wave0', 'wait_other_waves', 'merge_write', 'total'), out))
 
     def screen_stats(self):
         out = (C.c_int64 * 4)()

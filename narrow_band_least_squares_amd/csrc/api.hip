@@ -150,7 +150,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
                     h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -364,6 +364,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         h->screen_batch = batch;
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
         if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (8 + WP_ / 32) * sizeof(double)))) return rc;
+        if (getenv("NBLS_SCREEN_STAMPS")) {
+            if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * 8 * sizeof(unsigned long long)))) return rc;
+        }
         if ((rc = ensure(h, &h->d_cand, &h->cap_cand, (size_t)batch * h->nchans * h->nchans * 32 * sizeof(int32_t)))) return rc;
     }
     h->lts = lts != nullptr;
@@ -543,6 +546,30 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
                 out4[2] += e[0];
                 if (e[0] > out4[3]) out4[3] = e[0];
             }
+    return NBLS_OK;
+}
+
+int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
+    // mean cycle counts of the screen kernel's phases over the workgroups of the last batch:
+    // out = {stage issue, stage barrier wait, compute (wave 0), wait for the other waves, merge+write, total}
+    if (!h || !out6) return NBLS_ERR_ARG;
+    if (!h->d_stamps) return fail(h, NBLS_ERR_STATE, "run with NBLS_SCREEN_STAMPS=1");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
+    const int64_t nwg = ((last + 7) / 8) * 8 * ((h->nchans + 1) / 2);
+    std::vector<unsigned long long> st((size_t)nwg * 8);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    int64_t cnt = 0;
+    for (int64_t g = 0; g < nwg; ++g) {
+        const unsigned long long* s = &st[(size_t)g * 8];
+        if (s[5] <= s[0] || s[5] - s[0] > 100000000ull) continue;
+        for (int i = 0; i < 5; ++i) out6[i] += (double)(s[i + 1] - s[i]);
+        out6[5] += (double)(s[5] - s[0]);
+        ++cnt;
+    }
+    for (int i = 0; i < 6; ++i) out6[i] /= (double)(cnt > 0 ? cnt : 1);
     return NBLS_OK;
 }
 

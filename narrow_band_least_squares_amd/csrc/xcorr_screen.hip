@@ -59,6 +59,7 @@ struct QArgs {
     // screen
     int S, PFB, CSB, CSA;
     int8_t boff[16];          // per-partner LDS skew in 16-byte slots (bank-conflict-free B reads)
+    unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
     int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
     // verify
@@ -89,11 +90,23 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     double* sm = qsm + (size_t)wv * (a.WP + a.WP / 16 + 2);
     double* e16 = sm + a.WP;                       // [WP/16] energy of each 16-sample group
     double mx = 0.0, ss = 0.0;
-    for (int n = lane; n < a.WP; n += 64) {
-        const double v = n < W ? src[n] : 0.0;
-        sm[n] = v;
-        mx = fmax(mx, fabs(v));
-        ss += v * v;
+    if ((((uintptr_t)src) & 15) == 0) {          // 16-byte loads: two samples per lane per instruction
+#pragma unroll 4
+        for (int n = 2 * lane; n < a.WP; n += 128) {
+            double2 v = make_double2(0.0, 0.0);
+            if (n + 1 < W) v = *(const double2*)(src + n);
+            else if (n < W) v.x = src[n];
+            *(double2*)(sm + n) = v;
+            mx = fmax(mx, fmax(fabs(v.x), fabs(v.y)));
+            ss += v.x * v.x + v.y * v.y;
+        }
+    } else {
+        for (int n = lane; n < a.WP; n += 64) {
+            const double v = n < W ? src[n] : 0.0;
+            sm[n] = v;
+            mx = fmax(mx, fabs(v));
+            ss += v * v;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmax(mx, __shfl_xor(mx, off, 64));
@@ -163,6 +176,10 @@ __device__ inline float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x
     MFMA_I8(AL, bh, C2);              \
     MFMA_I8(AL, bl, C3)
 
+__device__ inline void stamp(unsigned long long* p, int slot) {
+    if (p) { p[slot] = __builtin_amdgcn_s_memtime(); }
+}
+
 constexpr int TB = 4;            // tile steps processed together (they share the B fragments)
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -188,6 +205,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int ul = grp * 8 + (rem & 7);
     const int cp = rem >> 3;
     if (ul >= a.nu) return;
+    unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    stamp(stp, 0);
     const int half = wv >> 2;                        // which sliding channel of the pair
     const int ci = 2 * cp + half;
     const bool chan_ok = ci < N;                     // odd N: the last pair has one channel
@@ -265,7 +284,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             *(uint2*)(dst + (size_t)r * CSA) = o;
         }
     }
+    stamp(stp, 1);
     __syncthreads();
+    stamp(stp, 2);
 
     // ---- lane roles ----
     const int c = lane & 15, g = lane >> 4;
@@ -389,7 +410,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         SCREEN_EPILOGUE(TB, acc)
     }
 #undef SCREEN_EPILOGUE
+    stamp(stp, 3);
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
+    stamp(stp, 4);
     int* Mj = (int*)lds;                            // [2][16] ordered-int image of the maximum
     int* cnt = Mj + 32;                             // [2][16]
     int* klo = cnt + 32;                            // [2][16] interval in np.correlate index space
@@ -434,6 +457,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         else val = (e - 4 < n && e - 4 < KOUT) ? lst[hq * KOUT + e - 4] : 0;
         out[e] = val;
     }
+    stamp(stp, 5);
 }
 
 // ------------------------------------------------------------------ 3. verify (FP64)
@@ -543,8 +567,15 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     }
     for (int ch = wv; ch < N; ch += nwv) {
         const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + t0;
+        double* dst = vsm + (size_t)ch * W;
+        if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+#pragma unroll 10
+            for (int n = 2 * lane; n + 1 < W; n += 128) *(double2*)(dst + n) = *(const double2*)(src + n);
+            if ((W & 1) && lane == 0) dst[W - 1] = src[W - 1];
+        } else {
 #pragma unroll 4
-        for (int n = lane; n < W; n += 64) vsm[(size_t)ch * W + n] = src[n];
+            for (int n = lane; n < W; n += 64) dst[n] = src[n];
+        }
     }
     __syncthreads();
     for (int k0 = 0; k0 * nwv + wv < P; k0 += 4) {
@@ -702,6 +733,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     { const char* e = getenv("NBLS_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    a.stamps = h->d_stamps;
     {
         // solved once per array size (cached); a failed/over-budget search falls back to the linear
         // skew o[jj] = jj, which is correct and at most 2-way conflicted
@@ -719,7 +751,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const size_t vlds = (size_t)N * h->maxW * sizeof(double);
+    size_t vlds = (size_t)N * h->maxW * sizeof(double);
+    { const char* e = getenv("NBLS_VERIFY_GLOBAL"); if (e && atoi(e)) vlds = 1u << 30; }   // timing experiment
     if (vlds <= 80 * 1024) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
         if (e != hipSuccess) return e;
