@@ -345,18 +345,18 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     }
 
     {   // resolve "auto": int8 screening when the array/window fit it, else f64 MFMA, else plain VALU
-        int S_, PFB_, CSB_, CSA_, WP_;
+        int S_, PFB_, CSB_, CSA_, WP_, nsl_;
         size_t lds_;
-        const bool ok = h->d_xij && nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_);
+        const bool ok = h->d_xij && nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
         if (xcorr_impl == 3 && !ok)
             return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..16 channels and a window that fits LDS");
         if (xcorr_impl == 0 && ok) xcorr_impl = 3;
         h->xcorr_impl = xcorr_impl;
     }
     if (xcorr_impl == 3) {
-        int S_, PFB_, CSB_, CSA_, WP_;
+        int S_, PFB_, CSB_, CSA_, WP_, nsl_;
         size_t lds_;
-        (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_);
+        (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
         // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
         int64_t batch = (int64_t)(96ll << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
@@ -557,7 +557,7 @@ int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
-    const int64_t nwg = ((last + 7) / 8) * 8 * ((h->nchans + 1) / 2);
+    const int64_t nwg = ((last + 7) / 8) * 8 * h->nchans;   // upper bound (one or two channels per workgroup)
     std::vector<unsigned long long> st((size_t)nwg * 8);
     HIPCHK(h, hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) out6[i] = 0.0;

@@ -107,6 +107,6 @@ hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
-bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds);
+bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl);
 hipError_t nbls_launch_xcorr_screen(nbls_handle* h);
 hipError_t nbls_launch_probe_mfma_i8(nbls_handle* h, const int* da, const int* db, int* dout);

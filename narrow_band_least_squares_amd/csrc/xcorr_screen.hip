@@ -58,6 +58,7 @@ struct QArgs {
     int qms;                  // doubles per (unit, channel) record = 4 + WP/32 + 2
     // screen
     int S, PFB, CSB, CSA;
+    int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
     int8_t boff[16];          // per-partner LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int N = a.nchans;
-    const int NCP = (N + 1) / 2;                     // channel pairs per unit
+    const int NSL = a.nsl;
+    const int NCP = (N + NSL - 1) / NSL;             // workgroups (channel pairs or single channels) per unit
     // keep the workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so that
     // the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
     const int b = blockIdx.x;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
     stamp(stp, 0);
     const int half = wv >> 2;                        // which sliding channel of the pair
-    const int ci = 2 * cp + half;
+    const int ci = NSL * cp + half;
     const bool chan_ok = ci < N;                     // odd N: the last pair has one channel
     const int u = a.u0 + ul;
     const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
@@ -219,26 +221,31 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // LDS: channel images [N][2 limbs][CSB] (channel j skewed by boff[j] sixteen-byte slots so that the
     // B-fragment reads are bank-conflict free for every sliding channel), then per sliding channel the
     // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
+    // (with ONE sliding channel per workgroup its own image is not needed: N-1 slots, slot = partner index)
+    const int nimg = NSL == 2 ? N : N - 1;
     unsigned char* Bimg = lds;
-    unsigned char* Acop = Bimg + (size_t)N * 2 * CSB;
-    int* gmax = (int*)(Acop + (size_t)2 * 16 * CSA);  // [2][16] order-preserving int image of a float
+    unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
+    int* gmax = (int*)(Acop + (size_t)NSL * 16 * CSA);  // [2][16] order-preserving int image of a float
     if (tid < 32) gmax[tid] = (int)0x80000000;
 
     // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
     //      eight before the LDS stores so that their latencies overlap ----
     const int gB = (CSB - 256) / 16;                 // groups written per image (skew room excluded)
-    const int nitemB = 2 * N * gB;
+    const int nitemB = 2 * nimg * gB;
+    const int nthr = blockDim.x;
+    const int ci0 = NSL * cp;                        // (NSL == 1: the slot of channel ch is ch - (ch > ci0))
     if (!(a.ablate & 2))
-    for (int it0 = tid; it0 < nitemB; it0 += 512 * 8) {
+    for (int it0 = tid; it0 < nitemB; it0 += nthr * 8) {
         uint4 v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int item = it0 + q * 512;
+            const int item = it0 + q * nthr;
             v[q] = make_uint4(0, 0, 0, 0);
             if (item < nitemB) {
-                const int limb = item / (N * gB);
-                const int r2 = item % (N * gB);
-                const int ch = r2 / gB, g = r2 % gB;
+                const int limb = item / (nimg * gB);
+                const int r2 = item % (nimg * gB);
+                const int slot = r2 / gB, g = r2 % gB;
+                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
                 const int m = g * 16 - PFB;          // sample index of the first byte of this group
                 if (m >= 0 && m < WP)
                     v[q] = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
@@ -246,12 +253,13 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int item = it0 + q * 512;
+            const int item = it0 + q * nthr;
             if (item < nitemB) {
-                const int limb = item / (N * gB);
-                const int r2 = item % (N * gB);
-                const int ch = r2 / gB, g = r2 % gB;
-                *(uint4*)(Bimg + ((size_t)ch * 2 + limb) * CSB + 16 * a.boff[ch] + g * 16) = v[q];
+                const int limb = item / (nimg * gB);
+                const int r2 = item % (nimg * gB);
+                const int slot = r2 / gB, g = r2 % gB;
+                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
+                *(uint4*)(Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[ch] + g * 16) = v[q];
             }
         }
     }
@@ -259,10 +267,10 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
     const int gA = CSA / 8;
     if (!(a.ablate & 2))
-    for (int item = tid; item < 4 * gA; item += 512) {
+    for (int item = tid; item < 2 * NSL * gA; item += nthr) {
         const int hs = item / (2 * gA), r2 = item % (2 * gA);
         const int limb = r2 / gA, g = r2 % gA;
-        const int chs = 2 * cp + hs;
+        const int chs = NSL * cp + hs;
         if (chs >= N) continue;
         const int8_t* src = a.qbuf + (((int64_t)ul * N + chs) * 2 + limb) * WP;
         unsigned int sdw[4] = {0, 0, 0, 0};
@@ -308,7 +316,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
     const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
     const unsigned char* pAl = Al + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);
-    const unsigned char* pBh = Bimg + ((size_t)j * 2) * CSB + 16 * a.boff[j] + PFB + 16 * g - 16 * s;   // + n'
+    const int jslot = NSL == 2 ? j : jj;
+    const unsigned char* pBh = Bimg + ((size_t)jslot * 2) * CSB + 16 * a.boff[j] + PFB + 16 * g - 16 * s;   // + n'
     const unsigned char* pBl = pBh + CSB;
     int* gmaxh = gmax + 16 * half;
 
@@ -440,10 +449,10 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         }
     }
     __syncthreads();
-    for (int item = tid; item < 2 * NP * CSTRIDE; item += 512) {
+    for (int item = tid; item < NSL * NP * CSTRIDE; item += nthr) {
         const int hs = item / (NP * CSTRIDE), r2 = item % (NP * CSTRIDE);
         const int pj = r2 / CSTRIDE, e = r2 % CSTRIDE;
-        const int chs = 2 * cp + hs;
+        const int chs = NSL * cp + hs;
         if (chs >= N) continue;
         const int jabs = pj + (pj >= chs ? 1 : 0);
         int32_t* out = a.cand + (((int64_t)ul * N + chs) * N + jabs) * CSTRIDE;
@@ -692,7 +701,7 @@ static bool boff_dfs(int* o, int j, int N, int S, long* budget) {
 }
 
 // Eligibility + LDS size of the screening path.
-bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds) {
+bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl) {
     const int N = h->nchans;
     if (N < 3 || N > 16 || h->maxW < 64) return false;
     *S = 16 / (N - 1);
@@ -705,14 +714,19 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     csa = round_up(csa, 32);
     while (csa % 256 != 32) csa += 32;               // copy stride == 32 B (mod 256): conflict-free ds_read_b64
     *CSA = csa;
-    *lds = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 128;
+    // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
+    // LDS, else one sliding channel (4 waves, N-1 images)
+    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 128;
+    const size_t lds1 = (size_t)2 * (N - 1) * (*CSB) + (size_t)16 * csa + 128;
+    if (lds2 <= 80 * 1024) { *nsl = 2; *lds = lds2; }
+    else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
 }
 
 hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     QArgs a{};
     size_t lds = 0;
-    if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds)) return hipErrorInvalidValue;
+    if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl)) return hipErrorInvalidValue;
     const int N = h->nchans;
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
@@ -775,7 +789,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 16 + 2) * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + 1) / 2)), dim3(512), lds, h->stream, a);
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl)), dim3(256 * a.nsl), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vlds <= 80 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(a.nu), dim3(512), vlds, h->stream, a);
