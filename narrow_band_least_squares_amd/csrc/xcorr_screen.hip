@@ -399,6 +399,26 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const int klen = W - D0;
         const unsigned char* qa_h = pAh + D0;
         const unsigned char* qa_l = pAl + D0;
+        if (step == 32) {
+            // two lag blocks per tile step (7 partners, the 8-element array): tiles t+2 and t are 64
+            // bytes = one K step apart, so the A fragments of tiles 2,3 are next iteration's tiles 0,1
+            // and only half of the A fragments are read from LDS per K step
+            v4i a0h = ld_frag64(qa_h), a0l = ld_frag64(qa_l);
+            v4i a1h = ld_frag64(qa_h + 32), a1l = ld_frag64(qa_l + 32);
+            for (int n0 = (a.ablate & 1) ? klen : 0; n0 < klen; n0 += 64) {
+                const v4i bh = *(const v4i*)(pBh + n0);
+                const v4i bl = *(const v4i*)(pBl + n0);
+                const v4i a2h = ld_frag64(qa_h + n0 + 64);
+                const v4i a2l = ld_frag64(qa_l + n0 + 64);
+                const v4i a3h = ld_frag64(qa_h + n0 + 96);
+                const v4i a3l = ld_frag64(qa_l + n0 + 96);
+                TILE4(a0h, a0l, c00, c01, c02, c03);
+                TILE4(a1h, a1l, c10, c11, c12, c13);
+                TILE4(a2h, a2l, c20, c21, c22, c23);
+                TILE4(a3h, a3l, c30, c31, c32, c33);
+                a0h = a2h; a0l = a2l; a1h = a3h; a1l = a3l;
+            }
+        } else
         for (int n0 = (a.ablate & 1) ? klen : 0; n0 < klen; n0 += 64) {
             const v4i bh = *(const v4i*)(pBh + n0);
             const v4i bl = *(const v4i*)(pBl + n0);
