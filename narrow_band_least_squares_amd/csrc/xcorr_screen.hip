@@ -231,65 +231,104 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
     //      eight before the LDS stores so that their latencies overlap ----
     const int gB = (CSB - 256) / 16;                 // groups written per image (skew room excluded)
-    const int nitemB = 2 * nimg * gB;
     const int nthr = blockDim.x;
     const int ci0 = NSL * cp;                        // (NSL == 1: the slot of channel ch is ch - (ch > ci0))
-    if (!(a.ablate & 2))
-    for (int it0 = tid; it0 < nitemB; it0 += nthr * 8) {
-        uint4 v[8];
+    // Staging is laid out by rows so that no integer division is needed: wave w takes image rows
+    // (slot, limb) = w, w + nwaves, ... and its lanes the 16-byte groups of the row; the sliding
+    // channels' rows (channel, limb) are taken by two waves each.  All global loads of a pass are
+    // issued before the LDS stores so that their round trips overlap.
+    const int gA = CSA / 8;
+    const int nwaves = nthr >> 6;
+    const int nrowB = 2 * nimg;
+    const int nrowA = 2 * NSL;                       // 4 or 2; nwaves / nrowA == 2
+    const int rowA = wv & (nrowA - 1), subA = wv >> (NSL == 2 ? 2 : 1);
+    const int hsA = rowA >> 1, limbA = rowA & 1;
+    const int chsA = NSL * cp + hsA;
+    const bool stage_on = !(a.ablate & 2);
+    const int8_t* srcA = a.qbuf + (((int64_t)ul * N + (chsA < N ? chsA : 0)) * 2 + limbA) * WP;
+    unsigned char* dstA = Acop + ((size_t)(hsA * 2 + limbA) * 8) * CSA;
+    // first pass of the sliding rows (128 groups = 1024 samples per row pass)
+    unsigned int asd[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int item = it0 + q * nthr;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (item < nitemB) {
-                const int limb = item / (nimg * gB);
-                const int r2 = item % (nimg * gB);
-                const int slot = r2 / gB, g = r2 % gB;
-                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
-                const int m = g * 16 - PFB;          // sample index of the first byte of this group
-                if (m >= 0 && m < WP)
-                    v[q] = *(const uint4*)(a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP + m);
+    for (int pa = 0; pa < 2; ++pa) {
+        const int g = subA * 64 + lane + pa * 128;
+        if (stage_on && chsA < N && g < gA) {
+            if (g * 8 < WP) {
+                const uint2 lo2 = *(const uint2*)(srcA + g * 8);
+                asd[pa][0] = lo2.x; asd[pa][1] = lo2.y;
+            }
+            if (g * 8 + 8 < WP) {
+                const uint2 hi2 = *(const uint2*)(srcA + g * 8 + 8);
+                asd[pa][2] = hi2.x; asd[pa][3] = hi2.y;
             }
         }
+    }
+    if (stage_on)
+    for (int row0 = wv; row0 < nrowB; row0 += 2 * nwaves) {
+        for (int g0 = lane; g0 < gB; g0 += 256) {
+            uint4 v[2][4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int item = it0 + q * nthr;
-            if (item < nitemB) {
-                const int limb = item / (nimg * gB);
-                const int r2 = item % (nimg * gB);
-                const int slot = r2 / gB, g = r2 % gB;
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = row0 + rr * nwaves;
+                const int slot = row >> 1, limb = row & 1;
                 const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
-                *(uint4*)(Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[ch] + g * 16) = v[q];
+                const int8_t* src = a.qbuf + (((int64_t)ul * N + (row < nrowB ? ch : 0)) * 2 + limb) * WP;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = g0 + 64 * q;
+                    const int m = g * 16 - PFB;      // sample index of the first byte of this group
+                    v[rr][q] = make_uint4(0, 0, 0, 0);
+                    if (row < nrowB && g < gB && m >= 0 && m < WP) v[rr][q] = *(const uint4*)(src + m);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = row0 + rr * nwaves;
+                const int slot = row >> 1, limb = row & 1;
+                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
+                unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[row < nrowB ? ch : 0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = g0 + 64 * q;
+                    if (row < nrowB && g < gB) *(uint4*)(dst + g * 16) = v[rr][q];
+                }
             }
         }
     }
     // ---- 8 byte-shifted copies of each sliding channel: A_r[m] = q_i[m + r], r = 0..7.  A lane's
     //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
-    const int gA = CSA / 8;
-    if (!(a.ablate & 2))
-    for (int item = tid; item < 2 * NSL * gA; item += nthr) {
-        const int hs = item / (2 * gA), r2 = item % (2 * gA);
-        const int limb = r2 / gA, g = r2 % gA;
-        const int chs = NSL * cp + hs;
-        if (chs >= N) continue;
-        const int8_t* src = a.qbuf + (((int64_t)ul * N + chs) * 2 + limb) * WP;
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+        const int g = subA * 64 + lane + pa * 128;
+        if (stage_on && chsA < N && g < gA) {
+            const unsigned int* sdw = asd[pa];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rw = r >> 2, rb = r & 3;
+                uint2 o;
+                o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
+                o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
+                *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
+            }
+        }
+    }
+    for (int g = subA * 64 + lane + 256; stage_on && chsA < N && g < gA; g += 128) {   // long windows
         unsigned int sdw[4] = {0, 0, 0, 0};
         if (g * 8 < WP) {
-            const uint2 lo2 = *(const uint2*)(src + g * 8);
+            const uint2 lo2 = *(const uint2*)(srcA + g * 8);
             sdw[0] = lo2.x; sdw[1] = lo2.y;
         }
         if (g * 8 + 8 < WP) {
-            const uint2 hi2 = *(const uint2*)(src + g * 8 + 8);
+            const uint2 hi2 = *(const uint2*)(srcA + g * 8 + 8);
             sdw[2] = hi2.x; sdw[3] = hi2.y;
         }
-        unsigned char* dst = Acop + ((size_t)(hs * 2 + limb) * 8) * CSA + g * 8;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int rw = r >> 2, rb = r & 3;
             uint2 o;
             o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
             o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
-            *(uint2*)(dst + (size_t)r * CSA) = o;
+            *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
         }
     }
     stamp(stp, 1);
@@ -330,7 +369,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int step = 16 * S;
     const int ntile = (W + step - 1) / step;
     const int ngrp4 = (ntile + TB - 1) / TB;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv & 3);
+    // the second sliding channel deals its groups in the opposite order: waves w and w+4 share a SIMD,
+    // and the groups' K ranges shrink with p, so every SIMD gets the same matrix-core work
+    const int wvu = __builtin_amdgcn_readfirstlane(half ? 3 - (wv & 3) : (wv & 3));
     // energy tables of the two channels of this lane's column (see quantize_kernel)
     const double* cum_i = mi + 4;
     const double* cum_j = mj + 4;
@@ -470,7 +511,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     }
     __syncthreads();
     for (int item = tid; item < NSL * NP * CSTRIDE; item += nthr) {
-        const int hs = item / (NP * CSTRIDE), r2 = item % (NP * CSTRIDE);
+        const int hs = item >= NP * CSTRIDE ? 1 : 0, r2 = item - hs * NP * CSTRIDE;
         const int pj = r2 / CSTRIDE, e = r2 % CSTRIDE;
         const int chs = NSL * cp + hs;
         if (chs >= N) continue;
