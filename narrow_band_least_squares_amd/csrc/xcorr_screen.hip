@@ -184,9 +184,14 @@ __device__ inline void stamp(unsigned long long* p, int slot) {
 constexpr int TB = 4;            // tile steps processed together (they share the B fragments)
 
 typedef int v2i __attribute__((ext_vector_type(2)));
-__device__ inline v4i ld_frag64(const unsigned char* p) {     // two aligned 8-byte LDS reads
-    const v2i lo = *(const v2i*)p;
-    const v2i hi = *(const v2i*)(p + 8);
+// Two aligned 8-byte LDS reads, volatile so that the compiler cannot fuse reads into ds_read2_b64
+// (neither the halves of one fragment nor the halves of two fragments): that form is serviced at half the
+// rate with 128-byte bank rows, for which copies r and r+4 of this layout collide (measured: 42 % of
+// the kernel's LDS cycles were conflict cycles).  Plain ds_read_b64 is conflict free here.
+__device__ inline v4i ld_frag64(const unsigned char* p) {
+    typedef const volatile v2i __attribute__((address_space(3))) * lds_v2i;
+    const v2i lo = *(lds_v2i)p;
+    const v2i hi = *(lds_v2i)(p + 8);
     return (v4i){lo[0], lo[1], hi[0], hi[1]};
 }
 
