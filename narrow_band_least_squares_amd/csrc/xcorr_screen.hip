@@ -36,9 +36,11 @@
 namespace {
 
 constexpr int QMAX = 16256;      // 127 * 128
-constexpr int KOUT = 28;         // candidates kept per ordered pair
+constexpr int KOUT = 26;         // candidates kept per ordered pair
 constexpr int NSLOT = 6;         // candidate slots per lane
-constexpr int CSTRIDE = KOUT + 4;   // count, flags (1 interval, 2 list overflow), kk_lo, kk_hi, kk[KOUT]
+constexpr int CHDR = 6;          // record header: count, flags (1 interval, 2 list overflow), kk_lo, kk_hi,
+                                 //                screening maximum of this direction (f32 bits), theta (f32 bits)
+constexpr int CSTRIDE = KOUT + CHDR;   // = 32 ints
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -492,11 +494,13 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     int* cnt = Mj + 32;                             // [2][16]
     int* klo = cnt + 32;                            // [2][16] interval in np.correlate index space
     int* khi = klo + 32;                            // [2][16]
-    int* lst = khi + 32;                            // [2][16][KOUT]
-    if (tid < 32) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; }
+    int* thS = khi + 32;                            // [2][16] theta of the pair (f32 bits)
+    int* lst = thS + 32;                            // [2][16][KOUT]
+    if (tid < 32) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; thS[tid] = 0; }
     __syncthreads();
     const int hj = 16 * half + jj;
     if (colvalid && lmax > -__builtin_inff()) atomicMax(&Mj[hj], f2ord(lmax));
+    if (colvalid && s == 0 && g == 0) thS[hj] = __float_as_int(theta);
     if (colvalid && ihi >= 0) {
         const int k1 = (ci < j) ? (W - 1 + ilo) : (W - 1 - ihi);
         const int k2 = (ci < j) ? (W - 1 + ihi) : (W - 1 - ilo);
@@ -529,7 +533,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         else if (e == 1) val = (khi[hq] >= 0 ? 1 : 0) | (n > KOUT ? 2 : 0);
         else if (e == 2) val = klo[hq];
         else if (e == 3) val = khi[hq];
-        else val = (e - 4 < n && e - 4 < KOUT) ? lst[hq * KOUT + e - 4] : 0;
+        else if (e == 4) val = __float_as_int(ord2f(Mj[hq]));
+        else if (e == 5) val = thS[hq];
+        else val = (e - CHDR < n && e - CHDR < KOUT) ? lst[hq * KOUT + e - CHDR] : 0;
         out[e] = val;
     }
     stamp(stp, 5);
@@ -542,23 +548,27 @@ __device__ inline bool better(double v1, int k1, double v2, int k2) {
 
 // Exact FP64 correlation values of up to four candidate indices at once (one wave; lanes stride the
 // samples, the partner sample is loaded once for the four).  Unused entries carry kk = -1.
-__device__ inline void wave_dot4(const double* xa, const double* xb, int W, const int (&kk)[4], int lane,
-                                 double (&out)[4]) {
-    int d[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+// NQ candidate lags of one pair at once: sum_n xa[n + d_q] * xb[n].  Out-of-window samples are read
+// from `zero` (a location holding 0.0 in the same memory as xa), which costs one select per sample
+// instead of a masked 64-bit value.
+template <int NQ>
+__device__ inline void wave_dot(const double* xa, const double* xb, const double* zero, int W, const int (&kk)[4],
+                                int lane, double (&out)[4]) {
+    int d[NQ];
+    double acc[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = kk[q] - (W - 1);
+    for (int q = 0; q < NQ; ++q) { d[q] = kk[q] - (W - 1); acc[q] = 0.0; }
     for (int n = lane; n < W; n += 64) {
         const double vb = xb[n];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int m = n + d[q];
-            const double va = (kk[q] >= 0 && m >= 0 && m < W) ? xa[m] : 0.0;
-            acc[q] = __builtin_fma(va, vb, acc[q]);
+            const double* pa = ((unsigned)m < (unsigned)W) ? xa + m : zero;
+            acc[q] = __builtin_fma(*pa, vb, acc[q]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         double v = acc[q];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         out[q] = v;
@@ -568,16 +578,25 @@ __device__ inline void wave_dot4(const double* xa, const double* xb, int W, cons
 // Verify one pair: xa/xb point at the two channel windows (LDS or global).  The two 32-int candidate
 // records are fetched with ONE load per lane (lanes 0-31: i->j record, 32-63: j->i) and read back with
 // wave-uniform shuffles, so the wave does not chase a chain of dependent global loads.
-__device__ inline void verify_pair(const double* xa, const double* xb, int W, int rec, double ssa, double ssb,
-                                   int lane, double* best_out, int* bestk_out) {
+// A direction whose screening maximum lies more than theta below the other direction's cannot hold
+// the arg-max (same test as inside the screening kernel) and is dropped without any FP64 work.
+__device__ inline void verify_pair(const double* xa, const double* xb, const double* zero, int W, int rec,
+                                   double ssa, double ssb, int lane, double* best_out, int* bestk_out) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
     if (ssa == 0.0 || ssb == 0.0) {          // dead channel: every lag is 0, np.argmax gives index 0
         best = 0.0;
         bestk = 0;
     } else {
-        const int n1 = __shfl(rec, 0, 64), f1 = __shfl(rec, 1, 64);
-        const int n2 = __shfl(rec, 32, 64), f2 = __shfl(rec, 33, 64);
+        int n1 = __shfl(rec, 0, 64), f1 = __shfl(rec, 1, 64);
+        int n2 = __shfl(rec, 32, 64), f2 = __shfl(rec, 33, 64);
+        const float M1 = __int_as_float(__shfl(rec, 4, 64)), M2 = __int_as_float(__shfl(rec, 36, 64));
+        const float th = __int_as_float(__shfl(rec, 5, 64));
+        const bool any1 = (n1 > 0) || f1, any2 = (n2 > 0) || f2;
+        if (any1 && any2 && th > 0.0f) {
+            if (M1 - th > M2) { n2 = 0; f2 = 0; }
+            else if (M2 - th > M1) { n1 = 0; f1 = 0; }
+        }
         const bool full = ((f1 | f2) & 2) || (n1 + n2 == 0 && !((f1 | f2) & 1));
         int r0lo = 0, r0hi = -1, r1lo = 0, r1hi = -1;
         if (full) { r0lo = 0; r0hi = 2 * W - 2; }
@@ -591,17 +610,21 @@ __device__ inline void verify_pair(const double* xa, const double* xb, int W, in
         const int total = nlist + nr0 + nr1;
         for (int q0 = 0; q0 < total; q0 += 4) {
             int kk[4];
-            double v[4];
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = q0 + q;
                 int val = -1;
-                if (idx < nlist) val = __shfl(rec, idx < n1 ? 4 + idx : 36 + idx - n1, 64);
+                if (idx < nlist) val = __shfl(rec, idx < n1 ? CHDR + idx : 32 + CHDR + idx - n1, 64);
                 else if (idx < nlist + nr0) val = r0lo + (idx - nlist);
                 else if (idx < total) val = r1lo + (idx - nlist - nr0);
                 kk[q] = val;
             }
-            wave_dot4(xa, xb, W, kk, lane, v);
+            const int nq = total - q0;                      // wave-uniform
+            if (nq >= 4) wave_dot<4>(xa, xb, zero, W, kk, lane, v);
+            else if (nq == 3) wave_dot<3>(xa, xb, zero, W, kk, lane, v);
+            else if (nq == 2) wave_dot<2>(xa, xb, zero, W, kk, lane, v);
+            else wave_dot<1>(xa, xb, zero, W, kk, lane, v);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (kk[q] >= 0 && better(v[q], kk[q], best, bestk)) { best = v[q]; bestk = kk[q]; }
@@ -652,6 +675,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
             for (int n = lane; n < W; n += 64) dst[n] = src[n];
         }
     }
+    if (tid == 0) vsm[(size_t)N * W] = 0.0;              // the zero slot of wave_dot
     __syncthreads();
     for (int k0 = 0; k0 * nwv + wv < P; k0 += 4) {
 #pragma unroll
@@ -670,7 +694,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
             }
             double best;
             int bestk;
-            verify_pair(vsm + (size_t)ci * W, vsm + (size_t)cj * W, W, rec, ssa, ssb, lane, &best, &bestk);
+            verify_pair(vsm + (size_t)ci * W, vsm + (size_t)cj * W, vsm + (size_t)N * W, W, rec, ssa, ssb, lane, &best, &bestk);
             if (lane == 0) {
                 const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
                 a.lag[o] = (W - 1) - bestk;
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
     const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
     const int rec = lane < 32 ? l1[lane] : l2[lane - 32];
     verify_pair(a.filt + ((int64_t)band * N + ci) * a.npts_pad + t0, a.filt + ((int64_t)band * N + cj) * a.npts_pad + t0,
-                W, rec, ssa, ssb, lane, &best, &bestk);
+                a.qmeta + 3 /* always 0.0 */, W, rec, ssa, ssb, lane, &best, &bestk);
     if (lane == 0) {
         const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
         a.lag[o] = (W - 1) - bestk;
@@ -831,7 +855,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    size_t vlds = (size_t)N * h->maxW * sizeof(double);
+    size_t vlds = ((size_t)N * h->maxW + 2) * sizeof(double);   // + the zero slot
     { const char* e = getenv("NBLS_VERIFY_GLOBAL"); if (e && atoi(e)) vlds = 1u << 30; }   // timing experiment
     if (vlds <= 80 * 1024) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
