@@ -551,6 +551,33 @@ __device__ inline bool better(double v1, int k1, double v2, int k2) {
 // NQ candidate lags of one pair at once: sum_n xa[n + d_q] * xb[n].  Out-of-window samples are read
 // from `zero` (a location holding 0.0 in the same memory as xa), which costs one select per sample
 // instead of a masked 64-bit value.
+// Sum of a double over the 64 lanes, same value in every lane: DPP permutations inside the 16-lane
+// rows (VALU latency, no trip through the LDS crossbar), then the four row sums through SGPRs.
+__device__ inline double dpp_mov_f64(double v, const int ctrl_sel) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2, hi2;
+    switch (ctrl_sel) {
+        case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;    // quad_perm [1,0,3,2]
+        case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;    // quad_perm [2,3,0,1]
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break;  // row_half_mirror
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
+    }
+    return __hiloint2double(hi2, lo2);
+}
+__device__ inline double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double wave_sum_f64(double v) {
+    v += dpp_mov_f64(v, 0);
+    v += dpp_mov_f64(v, 1);
+    v += dpp_mov_f64(v, 2);
+    v += dpp_mov_f64(v, 3);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// NQ candidate lags of one pair at once: sum_n xa[n + d_q] * xb[n].  Out-of-window samples are read
+// from `zero` (a location holding 0.0 in the same memory as xa), which costs one select per sample
+// instead of a masked 64-bit value.
 template <int NQ>
 __device__ inline void wave_dot(const double* xa, const double* xb, const double* zero, int W, const int (&kk)[4],
                                 int lane, double (&out)[4]) {
@@ -558,6 +585,7 @@ __device__ inline void wave_dot(const double* xa, const double* xb, const double
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { d[q] = kk[q] - (W - 1); acc[q] = 0.0; }
+#pragma unroll 4
     for (int n = lane; n < W; n += 64) {
         const double vb = xb[n];
 #pragma unroll
@@ -568,11 +596,7 @@ __device__ inline void wave_dot(const double* xa, const double* xb, const double
         }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double v = acc[q];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        out[q] = v;
-    }
+    for (int q = 0; q < NQ; ++q) out[q] = wave_sum_f64(acc[q]);
 }
 
 // Verify one pair: xa/xb point at the two channel windows (LDS or global).  The two 32-int candidate
@@ -588,10 +612,10 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
         best = 0.0;
         bestk = 0;
     } else {
-        int n1 = __shfl(rec, 0, 64), f1 = __shfl(rec, 1, 64);
-        int n2 = __shfl(rec, 32, 64), f2 = __shfl(rec, 33, 64);
-        const float M1 = __int_as_float(__shfl(rec, 4, 64)), M2 = __int_as_float(__shfl(rec, 36, 64));
-        const float th = __int_as_float(__shfl(rec, 5, 64));
+        int n1 = __builtin_amdgcn_readlane(rec, 0), f1 = __builtin_amdgcn_readlane(rec, 1);
+        int n2 = __builtin_amdgcn_readlane(rec, 32), f2 = __builtin_amdgcn_readlane(rec, 33);
+        const float M1 = __int_as_float(__builtin_amdgcn_readlane(rec, 4)), M2 = __int_as_float(__builtin_amdgcn_readlane(rec, 36));
+        const float th = __int_as_float(__builtin_amdgcn_readlane(rec, 5));
         const bool any1 = (n1 > 0) || f1, any2 = (n2 > 0) || f2;
         if (any1 && any2 && th > 0.0f) {
             if (M1 - th > M2) { n2 = 0; f2 = 0; }
@@ -601,8 +625,8 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
         int r0lo = 0, r0hi = -1, r1lo = 0, r1hi = -1;
         if (full) { r0lo = 0; r0hi = 2 * W - 2; }
         else {
-            if (f1 & 1) { r0lo = __shfl(rec, 2, 64); r0hi = __shfl(rec, 3, 64); }
-            if (f2 & 1) { r1lo = __shfl(rec, 34, 64); r1hi = __shfl(rec, 35, 64); }
+            if (f1 & 1) { r0lo = __builtin_amdgcn_readlane(rec, 2); r0hi = __builtin_amdgcn_readlane(rec, 3); }
+            if (f2 & 1) { r1lo = __builtin_amdgcn_readlane(rec, 34); r1hi = __builtin_amdgcn_readlane(rec, 35); }
         }
         const int nlist = full ? 0 : n1 + n2;
         const int nr0 = r0hi >= r0lo ? r0hi - r0lo + 1 : 0;
@@ -615,7 +639,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
             for (int q = 0; q < 4; ++q) {
                 const int idx = q0 + q;
                 int val = -1;
-                if (idx < nlist) val = __shfl(rec, idx < n1 ? CHDR + idx : 32 + CHDR + idx - n1, 64);
+                if (idx < nlist) val = __builtin_amdgcn_readlane(rec, idx < n1 ? CHDR + idx : 32 + CHDR + idx - n1);
                 else if (idx < nlist + nr0) val = r0lo + (idx - nlist);
                 else if (idx < total) val = r1lo + (idx - nlist - nr0);
                 kk[q] = val;
@@ -663,7 +687,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
             ssB[q] = a.qmeta[((int64_t)ul * N + cj) * a.qms];
         }
     }
-    for (int ch = wv; ch < N; ch += nwv) {
+    for (int ch = wv; ch < N && !(a.ablate & 128); ch += nwv) {
         const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + t0;
         double* dst = vsm + (size_t)ch * W;
         if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     }
     if (tid == 0) vsm[(size_t)N * W] = 0.0;              // the zero slot of wave_dot
     __syncthreads();
-    for (int k0 = 0; k0 * nwv + wv < P; k0 += 4) {
+    for (int k0 = (a.ablate & 64) ? P : 0; k0 * nwv + wv < P; k0 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = wv + (k0 + q) * nwv;
