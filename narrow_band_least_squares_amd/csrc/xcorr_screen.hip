@@ -75,9 +75,12 @@ struct QArgs {
 
 // ------------------------------------------------------------------ 1. quantize
 // One wave per (unit, channel).  The window is read once from global memory with lane-contiguous
-// 8-byte loads into the wave's LDS slab (max |x| and sum x^2 on the way); each lane then quantises
-// runs of 16 consecutive samples from LDS and stores two 16-byte limb groups, so that both the reads
-// and the writes of the kernel are coalesced.
+// loads into the wave's LDS slab (max |x| and sum x^2 on the way); each lane then quantises runs of 8
+// consecutive samples from LDS and stores two 8-byte limb groups, so that both the reads and the
+// writes of the kernel are coalesced.  The slab is padded by one double per 8 samples (index
+// n + n/8): lane g's reads at stride 9 doubles are bank-conflict free.
+__device__ inline int qpad(int n) { return n + (n >> 3); }
+
 __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     extern __shared__ double qsm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -90,8 +93,9 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
     const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
-    double* sm = qsm + (size_t)wv * (a.WP + a.WP / 16 + 2);
-    double* e16 = sm + a.WP;                       // [WP/16] energy of each 16-sample group
+    const int ng8 = a.WP / 8;
+    double* sm = qsm + (size_t)wv * (a.WP + ng8 + ng8 + 8);
+    double* e8 = sm + a.WP + ng8;                  // [WP/8] energy of each 8-sample group
     double mx = 0.0, ss = 0.0;
     if ((((uintptr_t)src) & 15) == 0) {          // 16-byte loads: two samples per lane per instruction
 #pragma unroll 4
@@ -99,14 +103,16 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
             double2 v = make_double2(0.0, 0.0);
             if (n + 1 < W) v = *(const double2*)(src + n);
             else if (n < W) v.x = src[n];
-            *(double2*)(sm + n) = v;
+            const int pn = qpad(n);
+            sm[pn] = v.x;
+            sm[pn + 1] = v.y;
             mx = fmax(mx, fmax(fabs(v.x), fabs(v.y)));
             ss += v.x * v.x + v.y * v.y;
         }
     } else {
         for (int n = lane; n < a.WP; n += 64) {
             const double v = n < W ? src[n] : 0.0;
-            sm[n] = v;
+            sm[qpad(n)] = v;
             mx = fmax(mx, fabs(v));
             ss += v * v;
         }
@@ -119,12 +125,15 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     int8_t* qh = a.qbuf + ((int64_t)ul * N + ch) * 2 * a.WP;
     int8_t* ql = qh + a.WP;
     long long l1 = 0;
-    for (int g = lane; g < a.WP / 16; g += 64) {
-        unsigned int ph[4] = {0, 0, 0, 0}, pl[4] = {0, 0, 0, 0};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int g = lane; g < ng8; g += 64) {
+        unsigned int ph[2] = {0, 0}, pl[2] = {0, 0};
         long long eg = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int q = (int)rint(sm[g * 16 + e] * scale);
+        for (int e = 0; e < 8; ++e) {
+            int q = (int)rint(sm[g * 9 + e] * scale);
             q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
             const int lo = ((q + 64) & 127) - 64;
             const int hi = (q - lo) >> 7;
@@ -133,9 +142,9 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
             ph[e >> 2] |= (unsigned int)(hi & 0xff) << (8 * (e & 3));
             pl[e >> 2] |= (unsigned int)(lo & 0xff) << (8 * (e & 3));
         }
-        *(uint4*)(qh + g * 16) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        *(uint4*)(ql + g * 16) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        e16[g] = (double)eg;
+        *(uint2*)(qh + g * 8) = make_uint2(ph[0], ph[1]);
+        *(uint2*)(ql + g * 8) = make_uint2(pl[0], pl[1]);
+        e8[g] = (double)eg;
     }
     for (int off = 32; off > 0; off >>= 1) l1 += __shfl_xor(l1, off, 64);
     double* m = a.qmeta + ((int64_t)ul * N + ch) * a.qms;
@@ -146,16 +155,35 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
         m[3] = 0.0;
     }
     // cumulative energy of the quantised window at 32-sample granularity (exact integers in double):
-    // cum[k] = sum_{n < 32k} q[n]^2, k = 0..WP/32+1 — the screening kernel bounds whole lag blocks with it
+    // cum[k] = sum_{n < 32k} q[n]^2, k = 0..WP/32+1 — the screening kernel bounds whole lag blocks with it.
+    // Lane k holds the energy of samples [32k, 32k+32); an inclusive scan over the lanes gives cum[k+1].
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ng16 = a.WP / 16;
-    for (int k = lane; k <= a.WP / 32 + 1; k += 64) {
-        double acc = 0.0;
-        const int lim = 2 * k < ng16 ? 2 * k : ng16;
-        for (int g = 0; g < lim; ++g) acc += e16[g];
-        m[4 + k] = acc;
+    const int nk = a.WP / 32 + 1;                  // cum[0..nk]
+    for (int k0 = 0; k0 <= nk; k0 += 64) {         // (one round up to 2000-sample windows)
+        const int k = k0 + lane;
+        double pk = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk += (4 * k + i < ng8) ? e8[4 * k + i] : 0.0;
+        double incl = pk;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        // carry of the previous rounds: cum[k0] already stored by this wave
+        double base = 0.0;
+        if (k0 > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            base = e8[ng8 + 0];
+        }
+        if (k + 1 <= nk) m[4 + k + 1] = base + incl;
+        if (k0 == 0 && lane == 0) m[4] = 0.0;
+        if (k0 + 64 <= nk) {                       // keep the running total for the next round
+            if (lane == 63) e8[ng8 + 0] = base + incl;
+        }
     }
 }
 
@@ -900,7 +928,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
         hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
-        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 16 + 2) * sizeof(double), h->stream, a);
+        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 4 + 8) * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl)), dim3(256 * a.nsl), lds, h->stream, a);
