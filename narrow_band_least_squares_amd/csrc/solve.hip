@@ -20,6 +20,7 @@
 // rule, r_k = (y_k - x_k0 z0) - x_k1 z1, h-subset by stable rank of |r_k|, objective summed
 // over the subset in ascending k.  With identical lags the LTS decisions are then identical.
 #include "nbls_internal.h"
+#include "lts_sortnet.inc"
 #include <utility>
 #include <cstdlib>
 
@@ -579,6 +580,48 @@ __device__ inline void subset_reg(const double (&a)[PT], double T, int kstar, un
     (one(std::integral_constant<int, K>{}), ...);
 }
 
+// Sorting networks for the pair counts of 4..8 element arrays (tools/gen_sortnet.py).
+#define NBLS_CE(I, J)                              \
+    {                                              \
+        const double lo_ = fmin(v[I], v[J]);       \
+        const double hi_ = fmax(v[I], v[J]);       \
+        v[I] = lo_;                                \
+        v[J] = hi_;                                \
+    }
+template <int PT> struct SortNet;
+template <> struct SortNet<6> { static __device__ __forceinline__ void run(double (&v)[6]) { NBLS_SORTNET_6(NBLS_CE) } };
+template <> struct SortNet<10> { static __device__ __forceinline__ void run(double (&v)[10]) { NBLS_SORTNET_10(NBLS_CE) } };
+template <> struct SortNet<15> { static __device__ __forceinline__ void run(double (&v)[15]) { NBLS_SORTNET_15(NBLS_CE) } };
+template <> struct SortNet<21> { static __device__ __forceinline__ void run(double (&v)[21]) { NBLS_SORTNET_21(NBLS_CE) } };
+template <> struct SortNet<28> { static __device__ __forceinline__ void run(double (&v)[28]) { NBLS_SORTNET_28(NBLS_CE) } };
+#undef NBLS_CE
+
+template <int PT, int... K>
+__device__ inline void copy_reg(double (&v)[PT], const double (&a)[PT], std::integer_sequence<int, K...>) {
+    ((v[K] = a[K]), ...);
+}
+
+template <int PT, int... K>
+__device__ inline void pick_sorted(const double (&v)[PT], int h, double& T, std::integer_sequence<int, K...>) {
+    // h-1 >= PT/2 (h > P/2 for every alpha); wave-uniform compares
+    ((T = (K >= PT / 2 && K == h - 1) ? v[K] : T), ...);
+}
+
+// h-subset for a threshold T that no tie straddles: in_k = (a_k <= T).  cnt tells the caller whether
+// that holds (cnt == h).  obj as fit_sums: obj + a^2*w in one fma (a^2 rounded first).
+template <int PT, int... K>
+__device__ inline void subset_le(const double (&a)[PT], double T, unsigned int& mask, int& cnt, double& obj,
+                                 std::integer_sequence<int, K...>) {
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned int in = (a[k] <= T) ? 1u : 0u;
+        cnt += (int)in;
+        obj = __builtin_fma(a[k] * a[k], (double)in, obj);
+        mask |= in << k;
+    };
+    (one(std::integral_constant<int, K>{}), ...);
+}
+
 template <int PT>
 __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* X0, const double* X1, int h,
                                         double z0, double z1) {
@@ -592,6 +635,27 @@ __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* 
     s.mask = 0ull;
     s.obj = dnan();
     s.ok = false;
+    // Usual case: the h-th smallest |r| from a sorting network (min/max pairs, no rank counting), the
+    // subset by one compare per pair.  Same subset and objective as the stable-rank definition unless
+    // a tie straddles position h (then cnt != h) or the fit is not finite: those lanes take the
+    // rank-counting path below.
+    if (fabs(z0) < 1.0e100 && fabs(z1) < 1.0e100) {
+        double v[PT];
+        copy_reg<PT>(v, a, Seq{});
+        SortNet<PT>::run(v);
+        double T = v[PT - 1];
+        pick_sorted<PT>(v, h, T, Seq{});
+        unsigned int m = 0u;
+        int cnt = 0;
+        double obj = 0.0;
+        subset_le<PT>(a, T, m, cnt, obj, Seq{});
+        if (cnt == h) {
+            s.ok = true;
+            s.mask = (unsigned long long)m;
+            s.obj = obj;
+            return s;
+        }
+    }
     double T = 0.0;
     int kstar = -1;
     find_threshold<PT>(a, h, T, kstar, Seq{});
@@ -606,18 +670,22 @@ __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* 
 }
 
 // Normal equations over the masked pairs from the product tables (ascending k), Cramer.
+// sum + t*w with w = 0.0 / 1.0 as ONE fma: t*w is exact, so the fma rounds exactly like "sum + t" (or
+// leaves the sum unchanged) -- same bits as a conditional add, one instruction per table entry.
 template <int PT, int... K>
 __device__ inline void fit_sums(const double* txx, const double* txy, const double* tyy, const double* tbx,
                                 const double* tby, unsigned long long mask, double& sxx, double& sxy,
                                 double& syy, double& bx, double& by, std::integer_sequence<int, K...>) {
+    const unsigned int mlo = (unsigned int)mask, mhi = (unsigned int)(mask >> 32);
     auto one = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const unsigned int in = (unsigned int)((mask >> k) & 1ull);
-        sxx = sxx + keep_if(txx[k], in);
-        sxy = sxy + keep_if(txy[k], in);
-        syy = syy + keep_if(tyy[k], in);
-        bx = bx + keep_if(tbx[k], in);
-        by = by + keep_if(tby[k], in);
+        const unsigned int in = k < 32 ? ((mlo >> k) & 1u) : ((mhi >> (k - 32)) & 1u);
+        const double w = (double)in;
+        sxx = __builtin_fma(txx[k], w, sxx);
+        sxy = __builtin_fma(txy[k], w, sxy);
+        syy = __builtin_fma(tyy[k], w, syy);
+        bx = __builtin_fma(tbx[k], w, bx);
+        by = __builtin_fma(tby[k], w, by);
     };
     (one(std::integral_constant<int, K>{}), ...);
 }
