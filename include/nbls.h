@@ -167,6 +167,10 @@ int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32
  * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
 int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
 /* Developer: mean s_memtime cycles of the screen kernel's phases (needs NBLS_SCREEN_STAMPS=1 at plan time). */
+/* Developer: mean s_memtime cycle counts of the phases of the wave-per-unit FAST-LTS kernel
+ * (run with NBLS_SCREEN_STAMPS=1 NBLS_LTS_STAMPS=1): out8 = {setup+medians, elemental starts,
+ * C-steps, candidate peel, refinement, finish, 0, total}. */
+int nbls_debug_lts_stamps(nbls_handle* h, double* out8);
 int nbls_debug_screen_stamps(nbls_handle* h, double* out6);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ EXPORTS = [
     'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
     'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
-    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps',
+    'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -87,6 +87,7 @@ def load_library(path=None):
     lib.nbls_debug_screen_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.nbls_set_window_ranges.argtypes = [vp, C.c_int32, ip, ip]
     lib.nbls_debug_screen_stamps.argtypes = [vp, dp]
+    lib.nbls_debug_lts_stamps.argtypes = [vp, dp]
     for name in EXPORTS:
         if name not in ('nbls_destroy', 'nbls_last_error'):
             getattr(lib, name).restype = C.c_int
@@ -257,6 +258,11 @@ class Handle:
         out = np.zeros(6)
         self._chk(self.lib.nbls_debug_screen_stamps(self._h, _dptr(out)))
         return dict(zip(('stage_issue', 'stage_wait', 'compute_wave0', 'wait_other_waves', 'merge_write', 'total'), out))
+
+    def lts_stamps(self):
+        out = np.zeros(8)
+        self._chk(self.lib.nbls_debug_lts_stamps(self._h, _dptr(out)))
+        return dict(zip(('setup_medians', 'elemental_starts', 'csteps', 'peel', 'refine', 'finish', 'nfin', 'total'), out))
 
     def screen_stats(self):
         out = (C.c_int64 * 4)()

@@ -573,6 +573,27 @@ int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     return NBLS_OK;
 }
 
+int nbls_debug_lts_stamps(nbls_handle* h, double* out8) {
+    if (!h || !out8) return NBLS_ERR_ARG;
+    if (!h->d_stamps || h->lts_stamp_waves <= 0) return fail(h, NBLS_ERR_STATE, "run with NBLS_SCREEN_STAMPS=1 NBLS_LTS_STAMPS=1");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> st((size_t)h->lts_stamp_waves * 8);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+    int64_t cnt = 0;
+    for (int64_t g = 0; g < h->lts_stamp_waves; ++g) {
+        const unsigned long long* s = &st[(size_t)g * 8];
+        if (s[6] <= s[0] || s[6] - s[0] > 1000000000ull) continue;
+        for (int i = 0; i < 6; ++i) out8[i] += (double)(s[i + 1] - s[i]);
+        out8[7] += (double)(s[6] - s[0]);
+        out8[6] += (double)s[7];              // finished entries entering the candidate peel
+        ++cnt;
+    }
+    for (int i = 0; i < 8; ++i) out8[i] /= (double)(cnt > 0 ? cnt : 1);
+    return NBLS_OK;
+}
+
 int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32_t* out) {
     if (!h || !a || !b || !out) return NBLS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));

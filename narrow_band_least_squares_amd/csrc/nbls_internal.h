@@ -79,6 +79,7 @@ struct nbls_handle {
     int32_t* d_cand = nullptr;     // [batch][N][N][16]
     size_t cap_qbuf = 0, cap_qmeta = 0, cap_cand = 0;
     int64_t screen_batch = 0;
+    int64_t lts_stamp_waves = 0;              // developer: waves of the last LTS launch that wrote stamps
     unsigned long long* d_stamps = nullptr;   // developer: s_memtime stamps of the screen kernel's workgroups
     size_t cap_stamps = 0;
 

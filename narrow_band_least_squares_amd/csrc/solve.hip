@@ -21,6 +21,7 @@
 // over the subset in ascending k.  With identical lags the LTS decisions are then identical.
 #include "nbls_internal.h"
 #include "lts_sortnet.inc"
+#include "wave_ops.h"
 #include <utility>
 #include <cstdlib>
 
@@ -56,6 +57,8 @@ struct SArgs {
     double zero_scale;
     int use_absr;
     int u0;                // first unit of this launch (unit batches of the pipelined path)
+    unsigned long long* stamps;   // developer (NBLS_LTS_STAMPS=1): 8 s_memtime stamps per wave, else NULL
+    int stamp_waves;
 };
 
 __device__ inline double dnan() { return __builtin_nan(""); }
@@ -747,6 +750,9 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     const int h = a.h;
     const int64_t o = (int64_t)band * a.vector_len + w;
 
+    const int wave_id = blockIdx.x * 4 + wv;
+    unsigned long long* stp = (a.stamps && lane == 0 && wave_id < a.stamp_waves) ? a.stamps + (size_t)wave_id * 8 : nullptr;
+    if (stp) stp[0] = __builtin_amdgcn_s_memtime();
     double* base = sm + (size_t)wv * slab_doubles;
     double* tauv = base;
     double* y = tauv + P;
@@ -814,6 +820,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     //      group is carried through the C-steps: typically 378 starts -> ~140 distinct subsets after the
     //      initial fit and a few dozen after the first C-step.  The merged starts would have finished
     //      with the same (objective, z) and be knocked out as duplicates by the candidate peel anyway.
+    if (stp) stp[1] = __builtin_amdgcn_s_memtime();
     unsigned long long* maskS = (unsigned long long*)objS;      // live entry: current h-subset
     double* prevS = z0S;                                        // live entry: previous objective
     for (int s0 = 0; s0 < S; s0 += 64) {
@@ -826,7 +833,17 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
                 if (idx >= 0) sm_ |= 1ull << idx;
             }
             double z0, z1;
-            fit_reg<PT>(txx, txy, tyy, tbx, tby, sm_, &z0, &z1);
+            const int i0 = a.starts[4 * s], i1 = a.starts[4 * s + 1];
+            if (a.starts[4 * s + 2] < 0 && i0 >= 0 && i1 >= 0 && i0 != i1) {
+                // two-point start: the sums have two terms (0 + t_i) + t_j, the same bits in either order
+                const double sxx = txx[i0] + txx[i1], sxy = txy[i0] + txy[i1], syy = tyy[i0] + tyy[i1];
+                const double bx = tbx[i0] + tbx[i1], by = tby[i0] + tby[i1];
+                const double det = sxx * syy - sxy * sxy;
+                z0 = (bx * syy - by * sxy) / det;
+                z1 = (by * sxx - bx * sxy) / det;
+            } else {
+                fit_reg<PT>(txx, txy, tyy, tbx, tby, sm_, &z0, &z1);
+            }
             const RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
             maskS[s] = sel.mask;
             prevS[s] = 0.0;
@@ -835,6 +852,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
         }
     }
     WSYNC();
+    if (stp) stp[2] = __builtin_amdgcn_s_memtime();
     int nact = S;
     for (int kk = 0; kk <= a.csteps; ++kk) {
         // -- rebuild the live list: drop dead/final entries and entries whose subset an earlier live
@@ -918,7 +936,59 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     WSYNC();
 
     // ---- peel off the ncand best distinct starts ----
+    if (stp) stp[3] = __builtin_amdgcn_s_memtime();
     int nc = 0;
+    // finished entries, compacted in start order (the live list is no longer needed)
+    int nfin = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool keep = s < S && stt[s] == 2;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) act[nfin + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)s;
+        nfin += __popcll(bal);
+    }
+    WSYNC();
+    if (stp) stp[7] = (unsigned long long)nfin;
+    if (nfin <= 128) {
+        // up to two finished entries per lane, the whole peel in registers: wave minimum of the
+        // objective; the lowest list position holding it is the lowest start index (slot 0 of every lane
+        // comes before slot 1); its duplicates (same objective and z) are dropped with it
+        int id[2];
+        double ov[2], w0[2], w1[2];
+        bool alive[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool have = lane + 64 * r < nfin;
+            id[r] = have ? act[lane + 64 * r] : 0;
+            ov[r] = have ? objS[id[r]] : dnan();
+            w0[r] = have ? z0S[id[r]] : 0.0;
+            w1[r] = have ? z1S[id[r]] : 0.0;
+            alive[r] = have;
+        }
+        for (int it = 0; it < a.ncand; ++it) {
+            const double c0 = alive[0] ? ov[0] : __builtin_inf(), c1 = alive[1] ? ov[1] : __builtin_inf();
+            const double m = nbls_wave::min_f64(fmin(c0, c1));
+            if (!(m < __builtin_inf())) break;       // nothing alive with a finite objective
+            const unsigned long long win0 = __ballot(alive[0] && ov[0] == m);
+            const unsigned long long win1 = __ballot(alive[1] && ov[1] == m);
+            double ww0, ww1;
+            int wid;
+            if (win0) {
+                const int wl = __builtin_ctzll(win0);
+                ww0 = nbls_wave::readlane_f64(w0[0], wl); ww1 = nbls_wave::readlane_f64(w1[0], wl);
+                wid = __builtin_amdgcn_readlane(id[0], wl);
+            } else {
+                const int wl = __builtin_ctzll(win1);
+                ww0 = nbls_wave::readlane_f64(w0[1], wl); ww1 = nbls_wave::readlane_f64(w1[1], wl);
+                wid = __builtin_amdgcn_readlane(id[1], wl);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (alive[r] && ov[r] == m && w0[r] == ww0 && w1[r] == ww1) alive[r] = false;
+            if (lane == 0) cand[nc] = wid;
+            ++nc;
+        }
+    } else
     for (int it = 0; it < a.ncand; ++it) {
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
@@ -943,6 +1013,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     }
     WSYNC();
     // ---- refine, one candidate per lane ----
+    if (stp) stp[4] = __builtin_amdgcn_s_memtime();
     if (lane < nc) {
         double z0 = z0S[cand[lane]], z1 = z1S[cand[lane]];
         RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
@@ -966,6 +1037,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
         cres[3 * lane + 2] = z1;
     }
     WSYNC();
+    if (stp) stp[5] = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
         double zr0 = dnan(), zr1 = dnan();
         double best = __builtin_inf();
@@ -1026,6 +1098,7 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     }
     WSYNC();
     if (lane < P) a.wts[o * P + lane] = wsh[lane];
+    if (stp) stp[6] = __builtin_amdgcn_s_memtime();
 }
 
 int lts_wave_slab_doubles(int P, int S) {
@@ -1103,6 +1176,17 @@ hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.rew = h->d_rew;
     a.quantile = h->ltsp.quantile;
     a.zero_scale = h->ltsp.zero_scale;
+    a.stamps = nullptr;
+    a.stamp_waves = 0;
+    {
+        const char* e = getenv("NBLS_LTS_STAMPS");
+        if (e && atoi(e) && h->d_stamps) {
+            a.stamps = h->d_stamps;
+            const int64_t cap = (int64_t)(h->cap_stamps / (8 * sizeof(unsigned long long)));
+            a.stamp_waves = (int)(nunits < cap ? nunits : cap);
+            h->lts_stamp_waves = a.stamp_waves;
+        }
+    }
     if (h->lts_impl != 1) {
         switch (h->npairs) {     // register-resident kernel for 4..8 elements (larger P spills registers)
             case 6: return launch_fast<6>(h, a, nunits, st);

@@ -37,6 +37,10 @@ def main():
         tot = st['total'] or 1.0
         print('screen stamps (mean cycles per workgroup, last batch):',
               {k: '%.0f (%.0f%%)' % (v, 100 * v / tot) for k, v in st.items()})
+    if os.environ.get('NBLS_LTS_STAMPS') == '1':
+        st = h.lts_stamps()
+        tot = st['total'] or 1.0
+        print('lts stamps (mean cycles per wave):', {k: '%.0f (%.0f%%)' % (v, 100 * v / tot) for k, v in st.items()})
     n = int(res.nwin[len(edges) // 2])
     print('mid band: median baz %.3f vel %.4f mdccm %.3f' % (np.nanmedian(res.baz[len(edges) // 2, :n]),
           np.nanmedian(res.vel[len(edges) // 2, :n]), np.nanmedian(res.mdccm[len(edges) // 2, :n])))
