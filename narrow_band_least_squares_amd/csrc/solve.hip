@@ -1038,7 +1038,10 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
     }
     WSYNC();
     if (stp) stp[5] = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
+    // ---- finish: best candidate -> de-standardise -> raw scale -> weights -> WLS refit -> reweighting.
+    //      Uniform values are computed by every lane (same cost as one lane); lane k < P owns pair k for the
+    //      residuals and the divisions of the weight tests; the order-sensitive sums stay sequential in k.
+    {
         double zr0 = dnan(), zr1 = dnan();
         double best = __builtin_inf();
         for (int c = 0; c < nc; ++c)
@@ -1047,57 +1050,63 @@ __global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nun
         zr1 = zr1 * tmad / a.xmad1;
         const bool finite_z = (zr0 - zr0 == 0.0) && (zr1 - zr1 == 0.0);
         if (!finite_z) {
-            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
-            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+            if (lane == 0) {
+                a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
+                a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
+            }
+            if (lane < P) a.wts[o * P + lane] = wsh[lane];
         } else {
+            const int k = lane < P ? lane : 0;
+            const double tk = tauv[k], c0 = x0[k], c1 = x1[k];
+            const unsigned long long pmask = (P < 64) ? ((1ull << P) - 1ull) : ~0ull;
             RegSel<PT> sel = select_reg<PT>(tauv, x0, x1, h, zr0, zr1);
             const double s0 = sqrt(sel.obj / (double)h) * a.raw_factor;
             double zf0 = zr0, zf1 = zr1;
+            const double rk0 = (tk - c0 * zr0) - c1 * zr1;
+            unsigned long long wm;
             if (fabs(s0) < a.zero_scale) {
-                for (int k = 0; k < P; ++k) wsh[k] = fabs(resid(tauv, x0, x1, k, zr0, zr1)) < a.zero_scale;
+                wm = __ballot(fabs(rk0) < a.zero_scale) & pmask;
             } else {
-                int nw = 0;
-                for (int k = 0; k < P; ++k) {
-                    const double r = resid(tauv, x0, x1, k, zr0, zr1);
-                    const uint8_t wk = fabs(r / s0) <= a.quantile;
-                    wsh[k] = wk;
-                    nw += wk;
+                wm = __ballot(fabs(rk0 / s0) <= a.quantile) & pmask;
+                int nw = __popcll(wm);
+                // product tables in original units (the C-step tables are no longer needed)
+                WSYNC();
+                if (lane < P) {
+                    txx[k] = c0 * c0;
+                    txy[k] = c0 * c1;
+                    tyy[k] = c1 * c1;
+                    tbx[k] = c0 * tk;
+                    tby[k] = c1 * tk;
                 }
-                fit_mask(tauv, x0, x1, P, wsh, &zf0, &zf1);
+                WSYNC();
+                fit_reg<PT>(txx, txy, tyy, tbx, tby, wm, &zf0, &zf1);
+                const double rk = (tk - c0 * zf0) - c1 * zf1;
+                if (lane < P) tmp[k] = rk * rk;
+                WSYNC();
                 double ssw = 0.0;
-                for (int k = 0; k < P; ++k) {
-                    if (wsh[k]) {
-                        const double r = resid(tauv, x0, x1, k, zf0, zf1);
-                        ssw = ssw + r * r;
-                    }
-                }
+                for (int q = 0; q < P; ++q) ssw = __builtin_fma(tmp[q], (double)(unsigned int)((wm >> q) & 1ull), ssw);
                 const double scale = nw > 1 ? sqrt(ssw / (double)(nw - 1)) * a.rew[nw] : 0.0;
-                if (scale > 0.0) {
-                    for (int k = 0; k < P; ++k) {
-                        const double r = resid(tauv, x0, x1, k, zf0, zf1);
-                        wsh[k] = fabs(r / scale) <= a.quantile;
-                    }
-                }
+                if (scale > 0.0) wm = __ballot(fabs(rk / scale) <= a.quantile) & pmask;
+                WSYNC();
             }
-            int nw = 0;
+            const double rkf = (tk - c0 * zf0) - c1 * zf1;
+            if (lane < P) tmp[k] = tk * rkf;
+            WSYNC();
+            const int nw = __popcll(wm);
             double acc = 0.0;
-            for (int k = 0; k < P; ++k) {
-                if (wsh[k]) {
-                    ++nw;
-                    acc = acc + tauv[k] * resid(tauv, x0, x1, k, zf0, zf1);
-                }
+            for (int q = 0; q < P; ++q) acc = __builtin_fma(tmp[q], (double)(unsigned int)((wm >> q) & 1ull), acc);
+            if (lane == 0) {
+                double vel, baz;
+                vel_baz(zf0, zf1, &vel, &baz);
+                a.vel[o] = vel;
+                a.baz[o] = baz;
+                a.sig[o] = nw > 2 ? sqrt(acc / (double)(nw - 2)) : dnan();
+                a.z[2 * o] = zf0;
+                a.z[2 * o + 1] = zf1;
             }
-            double vel, baz;
-            vel_baz(zf0, zf1, &vel, &baz);
-            a.vel[o] = vel;
-            a.baz[o] = baz;
-            a.sig[o] = nw > 2 ? sqrt(acc / (double)(nw - 2)) : dnan();
-            a.z[2 * o] = zf0;
-            a.z[2 * o + 1] = zf1;
+            if (lane < P) a.wts[o * P + lane] = (uint8_t)((wm >> lane) & 1ull);
         }
     }
-    WSYNC();
-    if (lane < P) a.wts[o * P + lane] = wsh[lane];
     if (stp) stp[6] = __builtin_amdgcn_s_memtime();
 }
 
