@@ -363,7 +363,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if (batch > U) batch = U > 0 ? U : 1;
         h->screen_batch = batch;
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
-        if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (8 + WP_ / 32) * sizeof(double)))) return rc;
+        if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (10 + WP_ / 32) * sizeof(double)))) return rc;
         if (getenv("NBLS_SCREEN_STAMPS")) {
             if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * 8 * sizeof(unsigned long long)))) return rc;
         }

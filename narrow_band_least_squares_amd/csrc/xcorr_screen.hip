@@ -7,11 +7,12 @@
 //  1. quantize  each channel window is scaled by its own max|x| to 15-bit integers q (|q| <= 16256)
 //               and split into two int8 limbs, q = 128*hi + lo, lo in [-64,63], hi in [-127,127].
 //  2. screen    the integer correlation I[d] = sum_n q_i[n+d] q_j[n] is computed EXACTLY for all lags
-//               with v_mfma_i32_16x16x64_i8 (four limb products, int32 accumulators, recombined as
-//               16384*HH + 128*(HL+LH) + LL).  Because |x*Q/s - q| <= 1/2, the true (scaled)
-//               correlation differs from I[d] by at most
-//                   eps = (sum|q_i| + sum|q_j|)/2 + W/4
-//               for every lag, so the true arg-max is among the lags with I[d] >= max I - 2 eps.
+//               with v_mfma_i32_16x16x64_i8 up to the product of the two low limbs: three limb products,
+//               int32 accumulators, I'[d] = 16384*HH + 128*(HL+LH); the dropped LL term is bounded by
+//               ||lo_i|| ||lo_j|| (Cauchy-Schwarz).  Because |x*Q/s - q| <= 1/2, the true (scaled)
+//               correlation differs from I'[d] by at most
+//                   eps = (sum|q_i| + sum|q_j|)/2 + W/4 + ||lo_i|| ||lo_j||
+//               for every lag, so the true arg-max is among the lags with I'[d] >= max I' - 2 eps.
 //               Each lane keeps the few lags of its accumulator rows that pass that test against its
 //               running maximum; an LDS atomic max + filter leaves the candidate list per ordered pair.
 //  3. verify    one wave per (unit, pair) evaluates the candidates' correlations in FP64 from the
@@ -56,8 +57,8 @@ struct QArgs {
     int u0, nu;               // unit batch
     int WP;                   // padded window bytes (multiple of 16)
     int8_t* qbuf;             // [nu][N][2][WP]
-    double* qmeta;            // [nu][N][qms]  ss, L1q, smax, 0, then cum[k] = sum of q^2 over samples < 32k
-    int qms;                  // doubles per (unit, channel) record = 4 + WP/32 + 2
+    double* qmeta;            // [nu][N][qms]  ss, L1q, smax, 0, then cum[k] = sum of q^2 over samples < 32k, then sum lo^2
+    int qms;                  // doubles per (unit, channel) record = 4 + WP/32 + 4
     // screen
     int S, PFB, CSB, CSA;
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     int8_t* qh = a.qbuf + ((int64_t)ul * N + ch) * 2 * a.WP;
     int8_t* ql = qh + a.WP;
     long long l1 = 0;
+    int l2lo = 0;                                  // sum of lo^2 (<= 4096 per sample)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
             const int lo = ((q + 64) & 127) - 64;
             const int hi = (q - lo) >> 7;
             l1 += q < 0 ? -q : q;
+            l2lo += lo * lo;
             eg += (long long)q * q;
             ph[e >> 2] |= (unsigned int)(hi & 0xff) << (8 * (e & 3));
             pl[e >> 2] |= (unsigned int)(lo & 0xff) << (8 * (e & 3));
@@ -146,13 +149,14 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
         *(uint2*)(ql + g * 8) = make_uint2(pl[0], pl[1]);
         e8[g] = (double)eg;
     }
-    for (int off = 32; off > 0; off >>= 1) l1 += __shfl_xor(l1, off, 64);
+    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_xor(l1, off, 64); l2lo += __shfl_xor(l2lo, off, 64); }
     double* m = a.qmeta + ((int64_t)ul * N + ch) * a.qms;
     if (lane == 0) {
         m[0] = ss;
         m[1] = (double)l1;
         m[2] = mx;
         m[3] = 0.0;
+        m[6 + a.WP / 32] = (double)l2lo;           // after cum[0 .. WP/32+1]
     }
     // cumulative energy of the quantised window at 32-sample granularity (exact integers in double):
     // cum[k] = sum_{n < 32k} q[n]^2, k = 0..WP/32+1 — the screening kernel bounds whole lag blocks with it.
@@ -200,12 +204,11 @@ __device__ inline int f2ord(float f) {
 __device__ inline float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 
 #define MFMA_I8(A_, B_, C_) C_ = __builtin_amdgcn_mfma_i32_16x16x64_i8(A_, B_, C_, 0, 0, 0)
-// the four limb products of one tile: HH, HL, LH, LL
-#define TILE4(AH, AL, C0, C1, C2, C3) \
-    MFMA_I8(AH, bh, C0);              \
-    MFMA_I8(AH, bl, C1);              \
-    MFMA_I8(AL, bh, C2);              \
-    MFMA_I8(AL, bl, C3)
+// limb products of one tile: HH into its own accumulator, HL and LH (both weighted 128) into a shared one
+#define TILE_H(AH, CH, CM) \
+    MFMA_I8(AH, bh, CH);   \
+    MFMA_I8(AH, bl, CM)
+#define TILE_L(AL, CM) MFMA_I8(AL, bh, CM)
 
 __device__ inline void stamp(unsigned long long* p, int slot) {
     if (p) { p[slot] = __builtin_amdgcn_s_memtime(); }
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
     const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
                             ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
-    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0) * 1.0001 + 1.0e-6 * iabs);
+    const double lolo = sqrt(mi[6 + WP / 32] * mj[6 + WP / 32]);           // bound of the dropped LL product
+    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
     const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * 8) * CSA;
     const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
     const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
@@ -421,8 +425,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                  \
             _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                         \
                 const int d = D0 + t * step + 16 * s + 4 * g + reg; /* i32 C/D: row = 4*(lane>>4)+reg */  \
-                const float x = 16384.0f * (float)ACC[t][0][reg]                                          \
-                                + 128.0f * (float)(ACC[t][1][reg] + ACC[t][2][reg]) + (float)ACC[t][3][reg]; \
+                const float x = 16384.0f * (float)ACC[t][0][reg] + 128.0f * (float)ACC[t][1][reg];        \
                 v[t * 4 + reg] = d < W ? x : -__builtin_inff();                                           \
                 gmx = fmaxf(gmx, v[t * 4 + reg]);                                                         \
             }                                                                                             \
@@ -468,36 +471,44 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             }
             if (__all(prunable)) continue;
         }
-        v4i c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c02 = {0, 0, 0, 0}, c03 = {0, 0, 0, 0};
-        v4i c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0}, c12 = {0, 0, 0, 0}, c13 = {0, 0, 0, 0};
-        v4i c20 = {0, 0, 0, 0}, c21 = {0, 0, 0, 0}, c22 = {0, 0, 0, 0}, c23 = {0, 0, 0, 0};
-        v4i c30 = {0, 0, 0, 0}, c31 = {0, 0, 0, 0}, c32 = {0, 0, 0, 0}, c33 = {0, 0, 0, 0};
+        v4i h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0}, h3 = {0, 0, 0, 0};   // HH per tile
+        v4i m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0}, m3 = {0, 0, 0, 0};   // HL + LH per tile
         const int klen = W - D0;
         const unsigned char* qa_h = pAh + D0;
         const unsigned char* qa_l = pAl + D0;
+        if (!(a.ablate & 1)) {
+        // the partner fragments of the NEXT K step are fetched while this step's products run
+        v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
         if (step == 32) {
             // two lag blocks per tile step (7 partners, the 8-element array): tiles t+2 and t are 64
             // bytes = one K step apart, so the A fragments of tiles 2,3 are next iteration's tiles 0,1
             // and only half of the A fragments are read from LDS per K step
             v4i a0h = ld_frag64(qa_h), a0l = ld_frag64(qa_l);
             v4i a1h = ld_frag64(qa_h + 32), a1l = ld_frag64(qa_l + 32);
-            for (int n0 = (a.ablate & 1) ? klen : 0; n0 < klen; n0 += 64) {
-                const v4i bh = *(const v4i*)(pBh + n0);
-                const v4i bl = *(const v4i*)(pBl + n0);
+            for (int n0 = 0; n0 < klen; n0 += 64) {
+                const int nn = n0 + 64 < klen ? n0 + 64 : n0;       // (the last step re-reads its own)
+                const v4i bhn = *(const v4i*)(pBh + nn);
+                const v4i bln = *(const v4i*)(pBl + nn);
                 const v4i a2h = ld_frag64(qa_h + n0 + 64);
                 const v4i a2l = ld_frag64(qa_l + n0 + 64);
                 const v4i a3h = ld_frag64(qa_h + n0 + 96);
                 const v4i a3l = ld_frag64(qa_l + n0 + 96);
-                TILE4(a0h, a0l, c00, c01, c02, c03);
-                TILE4(a1h, a1l, c10, c11, c12, c13);
-                TILE4(a2h, a2l, c20, c21, c22, c23);
-                TILE4(a3h, a3l, c30, c31, c32, c33);
+                TILE_H(a0h, h0, m0);
+                TILE_H(a1h, h1, m1);
+                TILE_L(a0l, m0);
+                TILE_L(a1l, m1);
+                TILE_H(a2h, h2, m2);
+                TILE_H(a3h, h3, m3);
+                TILE_L(a2l, m2);
+                TILE_L(a3l, m3);
                 a0h = a2h; a0l = a2l; a1h = a3h; a1l = a3l;
+                bh = bhn; bl = bln;
             }
         } else
-        for (int n0 = (a.ablate & 1) ? klen : 0; n0 < klen; n0 += 64) {
-            const v4i bh = *(const v4i*)(pBh + n0);
-            const v4i bl = *(const v4i*)(pBl + n0);
+        for (int n0 = 0; n0 < klen; n0 += 64) {
+            const int nn = n0 + 64 < klen ? n0 + 64 : n0;
+            const v4i bhn = *(const v4i*)(pBh + nn);
+            const v4i bln = *(const v4i*)(pBl + nn);
             const v4i a0h = ld_frag64(qa_h + n0);
             const v4i a0l = ld_frag64(qa_l + n0);
             const v4i a1h = ld_frag64(qa_h + n0 + step);
@@ -506,12 +517,18 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             const v4i a2l = ld_frag64(qa_l + n0 + 2 * step);
             const v4i a3h = ld_frag64(qa_h + n0 + 3 * step);
             const v4i a3l = ld_frag64(qa_l + n0 + 3 * step);
-            TILE4(a0h, a0l, c00, c01, c02, c03);
-            TILE4(a1h, a1l, c10, c11, c12, c13);
-            TILE4(a2h, a2l, c20, c21, c22, c23);
-            TILE4(a3h, a3l, c30, c31, c32, c33);
+            TILE_H(a0h, h0, m0);
+            TILE_H(a1h, h1, m1);
+            TILE_L(a0l, m0);
+            TILE_L(a1l, m1);
+            TILE_H(a2h, h2, m2);
+            TILE_H(a3h, h3, m3);
+            TILE_L(a2l, m2);
+            TILE_L(a3l, m3);
+            bh = bhn; bl = bln;
         }
-        const v4i acc[TB][4] = {{c00, c01, c02, c03}, {c10, c11, c12, c13}, {c20, c21, c22, c23}, {c30, c31, c32, c33}};
+        }
+        const v4i acc[TB][2] = {{h0, m0}, {h1, m1}, {h2, m2}, {h3, m3}};
         SCREEN_EPILOGUE(TB, acc)
     }
 #undef SCREEN_EPILOGUE
@@ -880,7 +897,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.unit_band = h->d_unit_band;
     a.qbuf = h->d_qbuf;
     a.qmeta = h->d_qmeta;
-    a.qms = 4 + a.WP / 32 + 2;
+    a.qms = 4 + a.WP / 32 + 4;                     // ss, L1, max, 0, cum[WP/32 + 2], sum lo^2, pad
     a.qms += a.qms & 1;
     a.cand = h->d_cand;
     a.npairs = h->npairs;
