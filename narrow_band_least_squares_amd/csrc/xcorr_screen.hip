@@ -369,11 +369,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
         }
     }
-    stamp(stp, 1);
-    __syncthreads();
-    stamp(stp, 2);
-
-    // ---- lane roles ----
+    // ---- lane roles (the pair records are fetched before the staging barrier: one round trip less) ----
     const int c = lane & 15, g = lane >> 4;
     const int ncol = NP * S;
     const bool colvalid = (c < ncol) && chan_ok;
@@ -390,6 +386,10 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
                             ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
     const double lolo = sqrt(mi[6 + WP / 32] * mj[6 + WP / 32]);           // bound of the dropped LL product
     const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
+    stamp(stp, 1);
+    __syncthreads();
+    stamp(stp, 2);
+
     const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * 8) * CSA;
     const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
     const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
