@@ -201,7 +201,7 @@ def main():
                          'flop_per_unit': flop_unit, 'kernel_ms_per_step': kern_ms,
                          'launches_per_step': int(h.timings()['xcorr_launches']),
                          'note': 'achieved = algorithmic 2*P*W^2 flop per unit x units / kernel time; the screening '
-                                 'kernel issues 4 int8 limb products per algorithmic multiply-add'},
+                                 'kernel issues 3 int8 limb products per algorithmic multiply-add (the low x low product is bounded, not computed)'},
             'roofline_hbm': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'bytes_per_unit': bytes_unit},
         }

@@ -737,7 +737,7 @@ __device__ inline double wave_nanmedian(const double* v, int P, double* srt, int
 // peel-off / refinement / finish stay inside the wave (shuffles + the wave's own LDS slab), so
 // there is no workgroup barrier and no idle wave during the serial tail.
 template <int PT>
-__global__ __launch_bounds__(256, 3) void solve_lts_wave_kernel(SArgs a, int nunits, int slab_doubles) {
+__global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nunits, int slab_doubles) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
