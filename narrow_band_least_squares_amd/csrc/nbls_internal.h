@@ -85,7 +85,7 @@ struct nbls_handle {
 
     // ---- LTS ----
     bool lts = false;
-    int lts_impl = 0;              // 0 auto, 1 generic kernel (NBLS_LTS_IMPL env, for A/B tests)
+    int lts_impl = 0;              // 0 auto, 1 generic kernel, 3 generic kernel only for pair counts without a register kernel (NBLS_LTS_IMPL env, for A/B tests)
     nbls_lts_params ltsp{};
     int32_t* d_starts = nullptr;   // [S][4]
     double* d_rew = nullptr;       // [P+1]

@@ -168,6 +168,28 @@ def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha):
     _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
 
 
+@pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5)])
+def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alpha):
+    """9..16 elements (36..120 pairs, 500 random starts): the wave-cooperative LTS kernel against the
+    oracle, and against the generic lane-per-start kernel (NBLS_LTS_IMPL=1) bit for bit."""
+    fs, npts = 20.0, 3000
+    rij = synthetic.array_geometry(nchans, 1.5)
+    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=nchans - 1, seed=11)
+    st = synthetic.make_stream(data, fs)
+    c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=st)
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 4.0, 2, 0.01)
+    _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
+    filt = np.array([tr.data for tr in stf_o])
+    t0 = oracle.start_datenum(stf_o[0].stats.starttime)
+    kw = dict(prefiltered=True, want_z=True)
+    a = engine.process(filt, fs, t0, c['rij'], [(None, None)], [30.0], 0.5, alpha, **kw)
+    monkeypatch.setenv('NBLS_LTS_IMPL', '1')
+    b = engine.process(filt, fs, t0, c['rij'], [(None, None)], [30.0], 0.5, alpha, **kw)
+    np.testing.assert_array_equal(a.z, b.z)
+    np.testing.assert_array_equal(a.weights, b.weights)
+    np.testing.assert_array_equal(a.sigma_tau, b.sigma_tau)
+
+
 def _compare_nbls(oracle, c, freq_resp, **kw):
     w = np.zeros(len(freq_resp)); h = np.zeros(len(freq_resp))
     args = (c['WINLEN_list'], c['overlap'], c['alpha'], None, None, None, c['NBANDS'], w, h, c['freqlist'],
