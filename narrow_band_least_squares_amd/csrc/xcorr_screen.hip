@@ -62,7 +62,8 @@ struct QArgs {
     // screen
     int S, PFB, CSB, CSA;
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
-    int8_t boff[16];          // per-partner LDS skew in 16-byte slots (bank-conflict-free B reads)
+    int npg;                  // partner groups per sliding channel (1 up to 17 elements)
+    int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
     int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
@@ -237,13 +238,15 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int lane = tid & 63, wv = tid >> 6;
     const int N = a.nchans;
     const int NSL = a.nsl;
-    const int NCP = (N + NSL - 1) / NSL;             // workgroups (channel pairs or single channels) per unit
+    const int NCP = (N + NSL - 1) / NSL;             // channel pairs (or single channels) per unit
+    const int NPG = a.npg;                           // partner groups of <= 16 partners (arrays of > 17 elements)
     // keep the workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so that
     // the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
     const int b = blockIdx.x;
-    const int grp = b / (8 * NCP), rem = b % (8 * NCP);
+    const int grp = b / (8 * NCP * NPG), rem = b % (8 * NCP * NPG);
     const int ul = grp * 8 + (rem & 7);
-    const int cp = rem >> 3;
+    const int cp = (rem >> 3) % NCP;
+    const int pg = (rem >> 3) / NCP;
     if (ul >= a.nu) return;
     unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
     stamp(stp, 0);
@@ -254,13 +257,14 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
     const int W = __builtin_amdgcn_readfirstlane(a.Wb[band]);      // wave-uniform: keeps the K loop scalar
     const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
-    const int NP = N - 1;
+    const int pgbase = 16 * pg;                      // first partner index of this workgroup's group
+    const int NP = (N - 1 - pgbase) < 16 ? (N - 1 - pgbase) : 16;   // partners handled here
 
     // LDS: channel images [N][2 limbs][CSB] (channel j skewed by boff[j] sixteen-byte slots so that the
     // B-fragment reads are bank-conflict free for every sliding channel), then per sliding channel the
     // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
     // (with ONE sliding channel per workgroup its own image is not needed: N-1 slots, slot = partner index)
-    const int nimg = NSL == 2 ? N : N - 1;
+    const int nimg = NSL == 2 ? N : NP;
     unsigned char* Bimg = lds;
     unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
     int* gmax = (int*)(Acop + (size_t)NSL * 16 * CSA);  // [2][16] order-preserving int image of a float
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = row0 + rr * nwaves;
                 const int slot = row >> 1, limb = row & 1;
-                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
+                const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
                 const int8_t* src = a.qbuf + (((int64_t)ul * N + (row < nrowB ? ch : 0)) * 2 + limb) * WP;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = row0 + rr * nwaves;
                 const int slot = row >> 1, limb = row & 1;
-                const int ch = NSL == 2 ? slot : slot + (slot >= ci0 ? 1 : 0);
+                const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
                 unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[row < nrowB ? ch : 0];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int jj = cc % NP;
     const int s = cc / NP;
     const int cis = chan_ok ? ci : 0;
-    const int j = jj + (jj >= cis ? 1 : 0);
+    const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);
     const double* mi = a.qmeta + ((int64_t)ul * N + cis) * a.qms;
     const double* mj = a.qmeta + ((int64_t)ul * N + j) * a.qms;
     // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const int pj = r2 / CSTRIDE, e = r2 % CSTRIDE;
         const int chs = NSL * cp + hs;
         if (chs >= N) continue;
-        const int jabs = pj + (pj >= chs ? 1 : 0);
+        const int jabs = pgbase + pj + (pgbase + pj >= chs ? 1 : 0);
         int32_t* out = a.cand + (((int64_t)ul * N + chs) * N + jabs) * CSTRIDE;
         const int hq = 16 * hs + pj;
         const int n = cnt[hq];
@@ -862,8 +866,9 @@ static bool boff_dfs(int* o, int j, int N, int S, long* budget) {
 // Eligibility + LDS size of the screening path.
 bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl) {
     const int N = h->nchans;
-    if (N < 3 || N > 16 || h->maxW < 64) return false;
-    *S = 16 / (N - 1);
+    if (N < 3 || N > 33 || h->maxW < 64) return false;
+    const int NPc = (N - 1) < 16 ? (N - 1) : 16;     // partners per workgroup (more than 16: partner groups)
+    *S = 16 / NPc;
     *PFB = 16 * (*S - 1);
     *WP = round_up(h->maxW, 16);
     // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
@@ -876,8 +881,8 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
     // LDS, else one sliding channel (4 waves, N-1 images)
     const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 128;
-    const size_t lds1 = (size_t)2 * (N - 1) * (*CSB) + (size_t)16 * csa + 128;
-    if (lds2 <= 80 * 1024) { *nsl = 2; *lds = lds2; }
+    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 128;
+    if (lds2 <= 80 * 1024 && N - 1 <= 16) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
 }
@@ -887,6 +892,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     size_t lds = 0;
     if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl)) return hipErrorInvalidValue;
     const int N = h->nchans;
+    a.npg = (N - 1 + 15) / 16;
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
     a.nchans = N;
@@ -911,16 +917,16 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         // solved once per array size (cached); a failed/over-budget search falls back to the linear
         // skew o[jj] = jj, which is correct and at most 2-way conflicted
         static int cache_n = -1;
-        static int cache_o[16];
+        static int cache_o[32];
         if (cache_n != N) {
-            int o[16] = {0};
+            int o[32] = {0};
             long budget = 200000;
-            if (!boff_dfs(o, 0, N, a.S, &budget))
-                for (int q = 0; q < 16; ++q) o[q] = q;
-            for (int q = 0; q < 16; ++q) cache_o[q] = o[q];
+            if (N > 16 || !boff_dfs(o, 0, N, a.S, &budget))
+                for (int q = 0; q < 32; ++q) o[q] = q & 15;   // consecutive partners of a group: distinct slots
+            for (int q = 0; q < 32; ++q) cache_o[q] = o[q];
             cache_n = N;
         }
-        for (int q = 0; q < 16; ++q) a.boff[q] = (int8_t)cache_o[q];
+        for (int q = 0; q < 32; ++q) a.boff[q] = (int8_t)cache_o[q];
     }
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -948,7 +954,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 4 + 8) * sizeof(double), h->stream, a);
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl)), dim3(256 * a.nsl), lds, h->stream, a);
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(256 * a.nsl), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vlds <= 80 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(a.nu), dim3(512), vlds, h->stream, a);
