@@ -168,7 +168,7 @@ def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha):
     _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
 
 
-@pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5)])
+@pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5), (20, 0.75), (32, 0.5)])
 def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alpha):
     """9..16 elements (36..120 pairs, 500 random starts): the wave-cooperative LTS kernel against the
     oracle, and against the generic lane-per-start kernel (NBLS_LTS_IMPL=1) bit for bit."""
