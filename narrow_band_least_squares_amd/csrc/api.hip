@@ -148,7 +148,7 @@ void nbls_destroy(nbls_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
-                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate,
+                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate, h->d_cstate2,
                     h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -317,6 +317,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const size_t nseries = (size_t)nbands * h->nchans;
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
+    if ((rc = ensure(h, &h->d_cstate2, &h->cap_cstate2, nseries * h->nchunks * D * sizeof(double)))) return rc;
     const size_t ngroups = (size_t)((h->nchunks + NBLS_FILTER_GROUP - 1) / NBLS_FILTER_GROUP);
     if ((rc = ensure(h, &h->d_gend, &h->cap_gend, nseries * ngroups * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_gin, &h->cap_gin, nseries * ngroups * D * sizeof(double)))) return rc;

@@ -51,6 +51,8 @@ struct FilterArgs {
     int64_t nchunks;
     int ngroups;
     int reverse;
+    int64_t plen;          // length of the pass's index space: npts forward, nchunks*C backward (see run_filter)
+    double* cstate_next;   // forward pass of a zero-phase filter: chunk states of the backward pass, else NULL
     int final_pass;
     const double* tl;
     const double* tr;
@@ -72,12 +74,13 @@ __global__ __launch_bounds__(256) void filter_state_kernel(FilterArgs a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.0;
     const int64_t p0 = chunk * C;
-    if (p0 + C <= a.npts) {          // the end state of a partial last chunk is never used
+    if (p0 + C <= a.plen) {          // the end state of a partial last chunk is never used
 #pragma unroll
         for (int k = 0; k < C / 64; ++k) {
             const int t = k * 64 + lane;
             const int64_t p = p0 + t;
-            const double x = in[a.reverse ? (a.npts - 1 - p) : p];
+            const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
+            const double x = g < a.npts ? in[g] : 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) acc[d] += fw[t * D + d] * x;
         }
@@ -208,6 +211,10 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         for (int s = 0; s < S; ++s) { s1[s] = st[2 * s]; s2[s] = st[2 * s + 1]; }
     }
 
+    const double* fwb = a.fw + (int64_t)band * C * D;
+    double e2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) e2[d] = 0.0;
     // tile (64 chunks x 32 samples): instruction i moves rows 2i, 2i+1 (256-B contiguous segments)
     double pre[T];
     auto fetch = [&](int ti) {
@@ -215,12 +222,13 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         for (int i = 0; i < T; ++i) {
             const int row = 2 * i + (lane >> 5);
             const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + (lane & 31);
-            pre[i] = p < a.npts ? in[a.reverse ? (a.npts - 1 - p) : p] : 0.0;
+            const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
+            pre[i] = (p < a.plen && g < a.npts) ? in[g] : 0.0;
         }
     };
     fetch(0);
     for (int ti = 0; ti < C / T; ++ti) {
-        if (chunk0 * C + (int64_t)ti * T >= a.npts) break;   // wave-uniform
+        if (chunk0 * C + (int64_t)ti * T >= a.plen) break;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < T; ++i) tile[2 * i + (lane >> 5)][lane & 31] = pre[i];
         __syncthreads();
@@ -236,6 +244,15 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
                 v = y;
             }
             tile[lane][t] = v;
+            if (a.cstate_next) {
+                // zero-state end state of the BACKWARD pass's chunk that covers the same samples
+                // (reversed): weight index C-1-tt; samples beyond the trace count as zeros there
+                const int tt = ti * T + t;
+                const double yv = (chunk * C + tt < a.npts) ? v : 0.0;
+                const double* wt = fwb + (size_t)(C - 1 - tt) * D;
+#pragma unroll
+                for (int d = 0; d < D; ++d) e2[d] += wt[d] * yv;
+            }
         }
         __syncthreads();
 #pragma unroll 4
@@ -243,8 +260,8 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
             const int row = 2 * i + (lane >> 5);
             const int col = lane & 31;
             const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
-            if (p < a.npts) {
-                const int64_t g = a.reverse ? (a.npts - 1 - p) : p;
+            const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
+            if (p < a.plen && g < a.npts) {
                 double v = tile[row][col];
                 if (a.final_pass) {
                     if (g < a.taper_len) v = v * a.tl[g];
@@ -255,12 +272,18 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         }
         __syncthreads();
     }
+    if (a.cstate_next && chunk < a.nchunks) {
+        double* st = a.cstate_next + ((a.nchunks - 1 - chunk) * a.nseries + q) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) st[d] = e2[d];
+    }
 }
 
 template <int S>
-hipError_t run_pass(nbls_handle* h, const FilterArgs& a) {
-    hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nseries),
-                       dim3(256), 0, h->stream, a);
+hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
+    if (!states_ready)
+        hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nseries),
+                           dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nseries + 63) / 64, a.ngroups), dim3(64), 0,
                        h->stream, a);
     hipLaunchKernelGGL((filter_carry_groups_kernel<S>), dim3((a.nseries + 63) / 64), dim3(64), 0, h->stream, a);
@@ -293,15 +316,25 @@ hipError_t run_filter(nbls_handle* h) {
     a.in_stride = h->npts_pad;
     a.in_mod = h->nchans;
     a.reverse = 0;
+    a.plen = h->npts;
     a.final_pass = h->zero_phase ? 0 : 1;
-    hipError_t e = run_pass<S>(h, a);
+    // zero-phase: the forward apply also accumulates the chunk states of the backward pass (it has
+    // every output sample in hand), which saves the backward pass's read of the whole buffer
+    const bool fuse = h->zero_phase && !getenv("NBLS_FILTER_NOFUSE");
+    a.cstate_next = fuse ? h->d_cstate2 : nullptr;
+    hipError_t e = run_pass<S>(h, a, false);
     if (e != hipSuccess || !h->zero_phase) return e;
-    // pass 2: in place, backward in time
+    // pass 2: in place, backward in time.  The backward index space is padded at its START to a whole
+    // number of chunks (zeros in, zero state: no effect on the output), so that its chunks coincide with
+    // the forward chunks: backward chunk c covers forward chunk nchunks-1-c.
     a.in = h->d_filt;
     a.in_mod = a.nseries;
     a.reverse = 1;
+    a.plen = h->nchunks * C;
     a.final_pass = 1;
-    return run_pass<S>(h, a);
+    a.cstate_next = nullptr;
+    if (fuse) a.cstate = h->d_cstate2;
+    return run_pass<S>(h, a, fuse);
 }
 
 // nsections == 0: the trace is already filtered; copy it (and apply the taper, if any).

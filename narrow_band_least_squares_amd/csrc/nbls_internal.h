@@ -63,6 +63,8 @@ struct nbls_handle {
     // ---- work + results ----
     double* d_filt = nullptr;      // [B][N][npts_pad]
     double* d_cstate = nullptr;    // [B*N][nchunks][D]
+    double* d_cstate2 = nullptr;   // same, for the backward pass (its chunk states are produced by the forward apply)
+    size_t cap_cstate2 = 0;
     int32_t* d_lag = nullptr;      // [B][VL][P]
     double* d_cmax = nullptr;      // [B][VL][P]
     double* d_vel = nullptr;       // [B][VL]
