@@ -171,6 +171,7 @@ template <int S>
 __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     constexpr int D = 2 * S;
     __shared__ double tile[64][T + 1];
+    __shared__ double wtile[T * D];      // backward-pass state weights of the tile's samples (fused states)
     const int lane = threadIdx.x;
     const int q = blockIdx.y;
     const int band = q / a.nchans;
@@ -231,6 +232,11 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         if (chunk0 * C + (int64_t)ti * T >= a.plen) break;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < T; ++i) tile[2 * i + (lane >> 5)][lane & 31] = pre[i];
+        if (a.cstate_next)
+            for (int idx = lane; idx < T * D; idx += 64) {
+                const int tl_ = idx / D, d = idx % D;
+                wtile[idx] = fwb[(size_t)(C - 1 - (ti * T + tl_)) * D + d];
+            }
         __syncthreads();
         if (ti + 1 < C / T) fetch(ti + 1);                    // in flight while this tile is filtered
 #pragma unroll 4
@@ -249,9 +255,8 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
                 // (reversed): weight index C-1-tt; samples beyond the trace count as zeros there
                 const int tt = ti * T + t;
                 const double yv = (chunk * C + tt < a.npts) ? v : 0.0;
-                const double* wt = fwb + (size_t)(C - 1 - tt) * D;
 #pragma unroll
-                for (int d = 0; d < D; ++d) e2[d] += wt[d] * yv;
+                for (int d = 0; d < D; ++d) e2[d] += wtile[t * D + d] * yv;
             }
         }
         __syncthreads();
