@@ -218,7 +218,19 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     for (int d = 0; d < D; ++d) e2[d] = 0.0;
     // tile (64 chunks x 32 samples): instruction i moves rows 2i, 2i+1 (256-B contiguous segments)
     double pre[T];
+    // all 64 chunks of this workgroup inside the trace (every workgroup but one): no per-sample bounds tests
+    const bool full = (chunk0 + 64) * C <= a.plen && (!a.reverse || chunk0 * C >= a.plen - a.npts) &&
+                      (a.reverse || (chunk0 + 64) * C <= a.npts);
     auto fetch = [&](int ti) {
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int row = 2 * i + (lane >> 5);
+                const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + (lane & 31);
+                pre[i] = in[a.reverse ? (a.plen - 1 - p) : p];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int row = 2 * i + (lane >> 5);
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
             const int col = lane & 31;
             const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
             const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
-            if (p < a.plen && g < a.npts) {
+            if (full || (p < a.plen && g < a.npts)) {
                 double v = tile[row][col];
                 if (a.final_pass) {
                     if (g < a.taper_len) v = v * a.tl[g];
