@@ -26,6 +26,7 @@
 // place.  The taper is multiplied in when the last pass writes.  HBM-bound by construction:
 // 2 reads + 1 write of 8 B per sample per pass.
 #include "nbls_internal.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -86,8 +87,7 @@ __global__ __launch_bounds__(256) void filter_state_kernel(FilterArgs a) {
         }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        for (int off = 32; off > 0; off >>= 1) acc[d] += __shfl_xor(acc[d], off, 64);
+    for (int d = 0; d < D; ++d) acc[d] = nbls_wave::sum_f64(acc[d]);
     if (lane == 0) {
         double* st = a.cstate + (chunk * a.nseries + q) * D;
 #pragma unroll
