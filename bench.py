@@ -136,8 +136,7 @@ def main():
         h.sync()
         if use_dist:
             ptrs, nbytes = h.device_results()
-            for p in ptrs[:4]:
-                dist.all_gather_device_grid(p, (len(edges), vector_len), np.float64, local_rank)
+            dist.all_gather_device_grids(ptrs, nbytes, (len(edges), vector_len), local_rank)
         else:
             h.fetch()
 

@@ -149,7 +149,7 @@ void nbls_destroy(nbls_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate, h->d_cstate2,
-                    h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts,
+                    h->d_lag, h->d_cmax, h->d_vel /* + baz, mdccm, sigma_tau */, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -325,20 +325,23 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const size_t cells = (size_t)nbands * vector_len;
     const size_t need = cells * sizeof(double);
     if (need > h->cap_res) {
-        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts};
+        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_z, h->d_wts};      // (baz, mdccm, sig live in d_vel's block)
         for (void* p : olds) if (p) (void)hipFree(p);
         h->d_lag = nullptr; h->d_cmax = nullptr; h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = h->d_z = nullptr; h->d_wts = nullptr;
         h->cap_res = 0;
     }
     if (!h->d_vel || h->cap_units < cells * P) {
-        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_baz, h->d_mdccm, h->d_sig, h->d_z, h->d_wts};
+        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_z, h->d_wts};
         for (void* p : olds) if (p) (void)hipFree(p);
+        h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = nullptr;
         HIPCHK(h, hipMalloc((void**)&h->d_lag, cells * P * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->d_cmax, cells * P * sizeof(double)));
-        HIPCHK(h, hipMalloc((void**)&h->d_vel, need));
-        HIPCHK(h, hipMalloc((void**)&h->d_baz, need));
-        HIPCHK(h, hipMalloc((void**)&h->d_mdccm, need));
-        HIPCHK(h, hipMalloc((void**)&h->d_sig, need));
+        // the four result grids are one block (vel | baz | mdccm | sigma_tau): a multi-GPU caller can
+        // all-gather them with one collective straight from HBM
+        HIPCHK(h, hipMalloc((void**)&h->d_vel, 4 * need));
+        h->d_baz = h->d_vel + cells;
+        h->d_mdccm = h->d_baz + cells;
+        h->d_sig = h->d_mdccm + cells;
         HIPCHK(h, hipMalloc((void**)&h->d_z, 2 * need));
         HIPCHK(h, hipMalloc((void**)&h->d_wts, cells * P));
         h->cap_res = need;

@@ -87,3 +87,24 @@ def all_gather_device_grid(ptr, shape, dtype=np.float64, device_index=0):
     outs = [torch.empty_like(t) for _ in range(world)]
     td.all_gather(outs, t)
     return [o.cpu().numpy() for o in outs]
+
+
+def all_gather_device_grids(ptrs, nbytes, shape, device_index=0):
+    """All-gather the four result grids (vel, baz, mdccm, sigma_tau) of every rank with ONE collective
+    when they are one contiguous block in HBM (the library allocates them so), else one per grid.
+    -> list over ranks of (4, *shape) float64 arrays."""
+    import torch
+    import torch.distributed as td
+    rank, world, backend = dist_info()
+    if backend != 'nccl':
+        raise RuntimeError('device-pointer gather needs the nccl backend')
+    cells = int(np.prod(shape))
+    contiguous = all(int(ptrs[i + 1]) - int(ptrs[i]) == nbytes for i in range(3)) and nbytes == cells * 8
+    if not contiguous:
+        per = [all_gather_device_grid(p, shape, np.float64, device_index) for p in ptrs[:4]]
+        return [np.stack([per[g][r] for g in range(4)]) for r in range(world)]
+    t = torch.as_tensor(_DevArray(ptrs[0], (4 * cells,), np.dtype(np.float64).str), device='cuda:%d' % device_index)
+    out = torch.empty((world, 4 * cells), dtype=torch.float64, device=t.device)
+    td.all_gather_into_tensor(out, t)
+    host = out.cpu().numpy()
+    return [host[r].reshape((4,) + tuple(shape)) for r in range(world)]
