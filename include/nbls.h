@@ -141,7 +141,9 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
 int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out);
 
 /* Device pointers of the result grids (for an RCCL gather straight from HBM):
- * ptrs[0..3] = vel, baz, mdccm, sigma_tau (double[nbands][vector_len]); ptrs[4] = nwin (int32). */
+ * ptrs[0..3] = vel, baz, mdccm, sigma_tau (double[nbands][vector_len]); ptrs[4] = nwin (int32).
+ * The four grids are allocated as one block: right after a plan that (re)allocated them they are
+ * contiguous (ptrs[i+1] - ptrs[i] == *bytes_per_grid), so one collective can move all four. */
 int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid);
 
 /* Enable (1) / disable (0) HIP-event timing of the stages; read the last run's timings. */
