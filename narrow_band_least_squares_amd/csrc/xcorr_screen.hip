@@ -32,6 +32,7 @@
 // processed together so that the B fragments are reused (LDS read bandwidth is the limiter: each
 // fragment pair feeds four MFMAs).
 #include "nbls_internal.h"
+#include "wave_ops.h"
 #include <cstdlib>
 
 namespace {
@@ -187,6 +188,117 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
         if (k + 1 <= nk) m[4 + k + 1] = base + incl;
         if (k0 == 0 && lane == 0) m[4] = 0.0;
         if (k0 + 64 <= nk) {                       // keep the running total for the next round
+            if (lane == 63) e8[ng8 + 0] = base + incl;
+        }
+    }
+}
+
+// Register form of quantize_kernel for windows up to 64*8*G samples: lane l owns the 8-sample groups
+// l, l+64, ... (G of them) and fetches them straight into registers (64-byte runs per lane, 4 KiB per
+// wave and pass), so the only LDS use is the small table of group energies.  Without the 12 KB slab per
+// wave the occupancy is set by registers, which is what hides the HBM latency of this streaming kernel.
+template <int G>
+__global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
+    extern __shared__ double qsm[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    const int N = a.nchans;
+    if (item >= a.nu * N) return;
+    const int ul = item / N, ch = item % N;
+    const int u = a.u0 + ul;
+    const int band = a.unit_band[u];
+    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
+    const int W = a.Wb[band];
+    const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
+    const int ng8 = a.WP / 8;
+    double* e8 = qsm + (size_t)wv * (ng8 + 8);     // [WP/8] energy of each 8-sample group (+ scan carry)
+    double x[G][8];
+    const bool al16 = (((uintptr_t)src) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int n0 = 8 * (lane + 64 * i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[i][e] = 0.0;
+        if (n0 + 8 <= W && al16) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const double2 v = *(const double2*)(src + n0 + e);
+                x[i][e] = v.x; x[i][e + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n0 + e < W) x[i][e] = src[n0 + e];
+        }
+    }
+    double mx = 0.0, ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx = fmax(mx, fabs(x[i][e])); ss += x[i][e] * x[i][e]; }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    ss = nbls_wave::sum_f64(ss);
+    const double scale = (mx > 0.0 && mx < __builtin_inf()) ? (double)QMAX / mx : 0.0;
+    int8_t* qh = a.qbuf + ((int64_t)ul * N + ch) * 2 * a.WP;
+    int8_t* ql = qh + a.WP;
+    long long l1 = 0;
+    int l2lo = 0;                                  // sum of lo^2 (<= 4096 per sample)
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ng8) {
+            unsigned int ph[2] = {0, 0}, pl[2] = {0, 0};
+            long long eg = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int q = (int)rint(x[i][e] * scale);
+                q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
+                const int lo = ((q + 64) & 127) - 64;
+                const int hi = (q - lo) >> 7;
+                l1 += q < 0 ? -q : q;
+                l2lo += lo * lo;
+                eg += (long long)q * q;
+                ph[e >> 2] |= (unsigned int)(hi & 0xff) << (8 * (e & 3));
+                pl[e >> 2] |= (unsigned int)(lo & 0xff) << (8 * (e & 3));
+            }
+            *(uint2*)(qh + g * 8) = make_uint2(ph[0], ph[1]);
+            *(uint2*)(ql + g * 8) = make_uint2(pl[0], pl[1]);
+            e8[g] = (double)eg;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_xor(l1, off, 64); l2lo += __shfl_xor(l2lo, off, 64); }
+    double* m = a.qmeta + ((int64_t)ul * N + ch) * a.qms;
+    if (lane == 0) {
+        m[0] = ss;
+        m[1] = (double)l1;
+        m[2] = mx;
+        m[3] = 0.0;
+        m[6 + a.WP / 32] = (double)l2lo;           // after cum[0 .. WP/32+1]
+    }
+    // cumulative energies as in quantize_kernel
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nk = a.WP / 32 + 1;                  // cum[0..nk]
+    for (int k0 = 0; k0 <= nk; k0 += 64) {
+        const int k = k0 + lane;
+        double pk = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk += (4 * k + i < ng8) ? e8[4 * k + i] : 0.0;
+        double incl = pk;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        double base = 0.0;
+        if (k0 > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            base = e8[ng8 + 0];
+        }
+        if (k + 1 <= nk) m[4 + k + 1] = base + incl;
+        if (k0 == 0 && lane == 0) m[4] = 0.0;
+        if (k0 + 64 <= nk) {
             if (lane == 63) e8[ng8 + 0] = base + incl;
         }
     }
@@ -951,7 +1063,17 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
         hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
-        hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 4 + 8) * sizeof(double), h->stream, a);
+        {
+            const int gpl = (a.WP / 8 + 63) / 64;          // 8-sample groups per lane
+            const size_t qlds = (size_t)4 * (a.WP / 8 + 8) * sizeof(double);
+            static const bool slab = getenv("NBLS_QUANTIZE_SLAB") != nullptr;   // developer: the LDS-slab form
+            if (gpl <= 4 && !slab)
+                hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
+            else if (gpl <= 8 && !slab)
+                hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
+            else
+                hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 4 + 8) * sizeof(double), h->stream, a);
+        }
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(256 * a.nsl), lds, h->stream, a);
