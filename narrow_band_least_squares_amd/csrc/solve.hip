@@ -1201,15 +1201,45 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
         if (i < PW && k < P)
             key[i] = (unsigned long long)__double_as_longlong(fabs((yv[k] - c0[k] * z0) - c1[k] * z1));
     }
-    unsigned long long T = 0ull;
-    for (int b = 62; b >= 0; --b) {
-        const unsigned long long cnd = T | (1ull << b);
+    // h-th smallest key, high word first (31 passes of 32-bit compares); the low word needs its own
+    // bisection only if several keys share the winning high word (rare for residuals)
+    unsigned int Thi = 0u;
+    for (int b = 30; b >= 0; --b) {
+        const unsigned int cnd = Thi | (1u << b);
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < PW) cnt += __popcll(__ballot(key[i] < cnd));
-        if (cnt <= h - 1) T = cnd;                   // the h-th smallest key is >= cnd
+            if (i < PW) cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) < cnd));
+        if (cnt <= h - 1) Thi = cnd;                 // the h-th smallest high word is >= cnd
     }
+    int clt_hi = 0, neq = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < PW) {
+            clt_hi += __popcll(__ballot((unsigned int)(key[i] >> 32) < Thi));
+            neq += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi));
+        }
+    unsigned int Tlo = 0u;
+    if (neq == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < PW) {
+                const unsigned long long eq = __ballot((unsigned int)(key[i] >> 32) == Thi);
+                if (eq) Tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[i], __builtin_ctzll(eq));
+            }
+    } else {
+        const int h2 = h - clt_hi;                   // rank (1-based) inside the keys that share Thi
+        for (int b = 31; b >= 0; --b) {
+            const unsigned int cnd = Tlo | (1u << b);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < PW)
+                    cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi && (unsigned int)key[i] < cnd));
+            if (cnt <= h2 - 1) Tlo = cnd;
+        }
+    }
+    const unsigned long long T = ((unsigned long long)Thi << 32) | Tlo;
     int clt = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
