@@ -150,15 +150,17 @@ def test_ltsva_eight_elements_lts(oracle):
     _compare_ltsva(oracle, c, stf_o, 30.0, 0.5)
 
 
-@pytest.mark.parametrize('alpha', [0.5, 0.75])
-def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha):
+@pytest.mark.parametrize('alpha,nine', [(0.5, False), (0.75, False), (0.5, True)])
+def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha, nine):
     """3x3 grid without its centre: many pairs share one baseline vector, so their residuals tie
     EXACTLY whenever their lags agree (the h-subset then hangs on the stable index order: the
     rank-counting path of the LTS kernel), and elemental starts made of two such pairs are singular
     (non-finite fit).  Everything must still equal the oracle: lags, z, weights, dropped elements."""
     fs, npts = 20.0, 6000
-    rij = np.array([(x, y) for x in (0.0, 0.3, 0.6) for y in (0.0, 0.3, 0.6)]).T[:, [0, 1, 2, 3, 5, 6, 7, 8]]
-    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=7, seed=7)
+    rij = np.array([(x, y) for x in (0.0, 0.3, 0.6) for y in (0.0, 0.3, 0.6)]).T
+    if not nine:
+        rij = rij[:, [0, 1, 2, 3, 5, 6, 7, 8]]      # 8 elements: register kernel; 9: the cooperative kernel
+    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=rij.shape[1] - 1, seed=7)
     st = synthetic.make_stream(data, fs)
     c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=st)
     stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 4.0, 2, 0.01)
