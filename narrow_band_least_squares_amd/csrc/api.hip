@@ -256,9 +256,10 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     h->unit_off.resize(nbands + 1);
     std::vector<int32_t> woff(nbands, 0);
     int64_t U = 0;
-    int maxW = 0;
+    int maxW = 0, uniW = nbands > 0 ? winlen[0] : 0;
     for (int b = 0; b < nbands; ++b) {
         const int W = winlen[b], inc = wininc[b];
+        if (W != uniW) uniW = 0;
         if (W < 2 || inc < 1 || (int64_t)W * 2 * sizeof(double) > 60 * 1024)
             return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2..3840 samples");
         // len(arange(0, npts - W, inc))
@@ -282,6 +283,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if (U > 0x7fffffffLL / (P > 0 ? P : 1)) return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: too many (unit, pair) items for one launch");
     h->nunits = U;
     h->maxW = maxW;
+    h->uniW = uniW;
     h->nbands = nbands;
     h->nsections = nsections;
     h->zero_phase = zero_phase ? 1 : 0;

@@ -43,6 +43,7 @@ struct nbls_handle {
     std::vector<int32_t> W, inc, nwin, unit_off;
     int64_t nunits = 0;
     int maxW = 0;
+    int uniW = 0;                  // the window length if every band has the same one, else 0
     int64_t nchunks = 0;
     double* d_sos = nullptr;       // [B][S][6]
     double* d_M = nullptr;         // [B][G+1][D][D] powers M^0..M^G of the chunk transition (D = 2S)

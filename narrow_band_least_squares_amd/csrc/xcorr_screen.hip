@@ -64,6 +64,7 @@ struct QArgs {
     int S, PFB, CSB, CSA;
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
     int npg;                  // partner groups per sliding channel (1 up to 17 elements)
+    int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int ci = NSL * cp + half;
     const bool chan_ok = ci < N;                     // odd N: the last pair has one channel
     const int u = a.u0 + ul;
-    const int band = __builtin_amdgcn_readfirstlane(a.unit_band[u]);
-    const int W = __builtin_amdgcn_readfirstlane(a.Wb[band]);      // wave-uniform: keeps the K loop scalar
+    // wave-uniform (keeps the K loop scalar); with one window length for all bands no load is needed
+    const int W = a.Wuni ? a.Wuni : __builtin_amdgcn_readfirstlane(a.Wb[__builtin_amdgcn_readfirstlane(a.unit_band[u])]);
     const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
     const int pgbase = 16 * pg;                      // first partner index of this workgroup's group
     const int NP = (N - 1 - pgbase) < 16 ? (N - 1 - pgbase) : 16;   // partners handled here
@@ -380,7 +381,20 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     unsigned char* Bimg = lds;
     unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
     int* gmax = (int*)(Acop + (size_t)NSL * 16 * CSA);  // [2][16] order-preserving int image of a float
-    if (tid < 32) gmax[tid] = (int)0x80000000;
+    // merge scalars [2][16] each (outside the images, so they can be initialised before the first barrier)
+    int* Mj = gmax + 32;                            // ordered-int image of the pair's maximum
+    int* cnt = Mj + 32;
+    int* klo = cnt + 32;                            // interval in np.correlate index space
+    int* khi = klo + 32;
+    int* thS = khi + 32;                            // theta of the pair (f32 bits)
+    // energy tables for the lag-block pruning, f32 rounded UP: tails of the sliding channels, prefix sums of all
+    const int NB = WP / 32 + 1;
+    float* tailT = (float*)(thS + 32);              // [NSL][NB + 1]  E_i[32k .. W)
+    float* cumT = tailT + NSL * (NB + 1);           // [N][NB + 1]    E_j[0 .. 32k)
+    if (tid < 32) {
+        gmax[tid] = (int)0x80000000;
+        Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; thS[tid] = 0;
+    }
 
     // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
     //      eight before the LDS stores so that their latencies overlap ----
@@ -416,6 +430,17 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
                 asd[pa][2] = hi2.x; asd[pa][3] = hi2.y;
             }
         }
+    }
+    // energy-table entry of this thread (f32 tables for the lag-block pruning): fetched now, stored after the images
+    const bool tab_on = tid < (NSL + N) * (NB + 1);
+    const int tab_row = tab_on ? tid / (NB + 1) : 0, tab_k = tab_on ? tid - tab_row * (NB + 1) : 0;
+    double tab_a = 0.0, tab_b = 0.0;
+    if (tab_on) {
+        const int chs = NSL * cp + tab_row;
+        const int chn = tab_row < NSL ? (chs < N ? chs : 0) : tab_row - NSL;
+        const double* m = a.qmeta + ((int64_t)ul * N + chn) * a.qms + 4;
+        tab_b = m[tab_k];
+        if (tab_row < NSL) tab_a = m[NB];
     }
     if (stage_on)
     for (int row0 = wv; row0 < nrowB; row0 += 2 * nwaves) {
@@ -485,6 +510,22 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
         }
     }
+    // ---- energy tables -> LDS (values fetched at the top of the kernel) ----
+    if (tab_on) {
+        if (tab_row < NSL) tailT[tab_row * (NB + 1) + tab_k] = __double2float_ru(tab_a - tab_b);
+        else cumT[(tab_row - NSL) * (NB + 1) + tab_k] = __double2float_ru(tab_b);
+    }
+    for (int idx = tid + nthr; idx < (NSL + N) * (NB + 1); idx += nthr) {      // (more than nthr entries: big arrays)
+        const int row = idx / (NB + 1), k = idx - row * (NB + 1);
+        if (row < NSL) {
+            const int chs = NSL * cp + row;
+            const double* m = a.qmeta + ((int64_t)ul * N + (chs < N ? chs : 0)) * a.qms + 4;
+            tailT[idx] = __double2float_ru(m[NB] - m[k]);
+        } else {
+            const double* m = a.qmeta + ((int64_t)ul * N + (row - NSL)) * a.qms + 4;
+            cumT[(row - NSL) * (NB + 1) + k] = __double2float_ru(m[k]);
+        }
+    }
     // ---- lane roles (the pair records are fetched before the staging barrier: one round trip less) ----
     const int c = lane & 15, g = lane >> 4;
     const int ncol = NP * S;
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // energy tables of the two channels of this lane's column (see quantize_kernel)
     const double* cum_i = mi + 4;
     const double* cum_j = mj + 4;
-    const int NB = WP / 32 + 1;
+    (void)cum_i; (void)cum_j;
 
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
 // 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
@@ -581,9 +622,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
                 const int kp = (W - D0 + 31) / 32 < NB ? (W - D0 + 31) / 32 : NB;
-                const double bound = sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]);
+                const float bound = sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f;
                 const float gm = ord2f(gmaxh[jj]);
-                prunable = (float)(bound * (1.0 + 1e-6) + 1.0e-6 * iabs) < gm - theta;
+                prunable = bound * 1.000001f + (float)(1.0e-6 * iabs) < gm - theta;
             }
             if (__all(prunable)) continue;
         }
@@ -651,14 +692,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     stamp(stp, 3);
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
     stamp(stp, 4);
-    int* Mj = (int*)lds;                            // [2][16] ordered-int image of the maximum
-    int* cnt = Mj + 32;                             // [2][16]
-    int* klo = cnt + 32;                            // [2][16] interval in np.correlate index space
-    int* khi = klo + 32;                            // [2][16]
-    int* thS = khi + 32;                            // [2][16] theta of the pair (f32 bits)
-    int* lst = thS + 32;                            // [2][16][KOUT]
-    if (tid < 32) { Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; thS[tid] = 0; }
-    __syncthreads();
+    int* lst = (int*)lds;                           // [2][16][KOUT] (aliases the images: they are done with)
     const int hj = 16 * half + jj;
     if (colvalid && lmax > -__builtin_inff()) atomicMax(&Mj[hj], f2ord(lmax));
     if (colvalid && s == 0 && g == 0) thS[hj] = __float_as_int(theta);
@@ -992,8 +1026,10 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     *CSA = csa;
     // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
     // LDS, else one sliding channel (4 waves, N-1 images)
-    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 128;
-    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 128;
+    // + running maxima and merge scalars (6 x 32 ints) + the f32 energy tables of the pruning test
+    const int NBt = *WP / 32 + 2;
+    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + (size_t)(2 + N) * NBt * 4 + 64;
+    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + (size_t)(1 + N) * NBt * 4 + 64;
     if (lds2 <= 80 * 1024 && N - 1 <= 16) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
@@ -1005,6 +1041,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl)) return hipErrorInvalidValue;
     const int N = h->nchans;
     a.npg = (N - 1 + 15) / 16;
+    a.Wuni = h->uniW;
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
     a.nchans = N;
