@@ -1090,6 +1090,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         }
         for (int q = 0; q < 32; ++q) a.boff[q] = (int8_t)cache_o[q];
     }
+    { const char* pe = getenv("NBLS_SCREEN_PAD_KB"); if (pe) lds += (size_t)atoi(pe) * 1024; }   // developer: occupancy experiment
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t vlds = ((size_t)N * h->maxW + 2) * sizeof(double);   // + the zero slot
