@@ -1043,7 +1043,8 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     const int NBt = *WP / 32 + 2;
     const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + (size_t)(2 + N) * NBt * 4 + 64;
     const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + (size_t)(1 + N) * NBt * 4 + 64;
-    if (lds2 <= 80 * 1024 && N - 1 <= 16) { *nsl = 2; *lds = lds2; }
+    static const bool force1 = getenv("NBLS_SCREEN_NSL1") != nullptr;    // developer: one sliding channel per workgroup
+    if (lds2 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
 }

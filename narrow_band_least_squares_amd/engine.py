@@ -164,13 +164,28 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                      xij=xij, nchans=nchans, alpha=alpha, handle=h)
 
 
-def stdict_from_weights(weights_row, nwin, t_row, pair_idx, nchans):
+def stdict_from_weights(weights_row, nwin, t_row, pair_idx, nchans, prefix=''):
     """lts_array's dropped-element dictionary for one band: key ``str(t)`` -> 1-based element
-    numbers of both members of every zero-weight pair; ``'size'`` -> number of elements."""
+    numbers of both members of every zero-weight pair (first members, then second members);
+    ``'size'`` -> number of elements.  ``prefix`` is put in front of every time key (the band prefix of
+    narrow_band_least_squares.py:114-124).  Vectorised: one pass over the weight grid, the values are
+    slices of one array (a 6 h / 48 band run has ~5*10^4 entries)."""
     stdict = {}
-    for w in range(nwin):
-        drop = np.where(weights_row[w] == 0)[0]
-        if len(drop) > 0:
-            stdict[str(t_row[w])] = np.concatenate((pair_idx[drop, 0] + 1, pair_idx[drop, 1] + 1))
+    nwin = int(nwin)
+    rows, cols = np.nonzero(np.asarray(weights_row[:nwin]) == 0)
+    if len(rows):
+        pair_idx = np.asarray(pair_idx)
+        counts = np.bincount(rows, minlength=nwin)
+        starts = np.cumsum(counts) - counts
+        local = np.arange(len(rows)) - starts[rows]
+        pos1 = 2 * starts[rows] + local
+        big = np.empty(2 * len(rows), dtype=(pair_idx[:1, 0] + 1).dtype)
+        big[pos1] = pair_idx[cols, 0] + 1
+        big[pos1 + counts[rows]] = pair_idx[cols, 1] + 1
+        nz = np.nonzero(counts)[0]
+        pieces = np.split(big, np.cumsum(2 * counts[nz])[:-1])
+        # repr of a Python float is the text str(numpy.float64) gives (shortest round-trip form)
+        keys = [prefix + repr(x) for x in np.asarray(t_row, dtype=np.float64)[nz].tolist()]
+        stdict = dict(zip(keys, pieces))
     stdict['size'] = nchans
     return stdict

@@ -41,6 +41,11 @@ def _bt_caution(winlen, fmin, fmax):
         print('CAUTION: BT < 5! Band between ' + str(fmin) + ' Hz and ' + str(fmax) + ' Hz has BT = ' + str(temp_BT))
 
 
+def _band_prefix(band_number):
+    """'<band:02d>_' as narrow_band_least_squares.py:114-124 builds it."""
+    return str(band_number).zfill(2) + '_'
+
+
 def _prefix_stdict(stdict, band_number):
     """Keys -> '<band:02d>_<key>', 'size' kept.  narrow_band_least_squares.py:114-124."""
     out = {}
@@ -99,9 +104,8 @@ def narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_lis
     else:
         stdict_all = {}
         for n, ii in enumerate(bands):
-            sd = engine.stdict_from_weights(res.weights[n], num_compute_list[n], res.t[n], res.pair_idx,
-                                            res.nchans)
-            stdict_all = {**stdict_all, **_prefix_stdict(sd, ii + 1)}
+            stdict_all.update(engine.stdict_from_weights(res.weights[n], num_compute_list[n], res.t[n], res.pair_idx,
+                                                         res.nchans, prefix=_band_prefix(ii + 1)))
         sig_tau_array = np.zeros_like(res.sigma_tau)
     return (res.vel, res.baz, res.mdccm, res.t, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
@@ -203,11 +207,11 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
             num_compute_list[b] = int(all_nwin[r][n])
             w_array[b], h_array[b] = rr[0, n], rr[1, n]
             if ALPHA < 1.0:
-                sd = engine.stdict_from_weights(all_wts[r][n], num_compute_list[b], t_array[b], pair_idx, nchans)
-                per_band_dict[b] = _prefix_stdict(sd, b + 1)
+                per_band_dict[b] = engine.stdict_from_weights(all_wts[r][n], num_compute_list[b], t_array[b], pair_idx,
+                                                              nchans, prefix=_band_prefix(b + 1))
     if ALPHA < 1.0:
         for b in range(NBANDS):
-            stdict_all = {**stdict_all, **per_band_dict[b]}
+            stdict_all.update(per_band_dict[b])
     return (vel_array, baz_array, mdccm_array, t_array, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
 
@@ -248,7 +252,7 @@ def _parallel_by_windows(rank, world, WINLEN_list, WINOVER, ALPHA, st, lat_list,
         # rows outside every slice do not exist (beyond num_compute); inside, exactly one rank wrote 0/1
         stdict_all = {}
         for n, ii in enumerate(bands):
-            sd = engine.stdict_from_weights(wts[n], num_compute_list[n], res.t[n], res.pair_idx, nchans)
-            stdict_all = {**stdict_all, **_prefix_stdict(sd, ii + 1)}
+            stdict_all.update(engine.stdict_from_weights(wts[n], num_compute_list[n], res.t[n], res.pair_idx, nchans,
+                                                         prefix=_band_prefix(ii + 1)))
         sig_tau_array = np.zeros_like(total[3])
     return (total[0], total[1], total[2], res.t, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)

@@ -13,6 +13,8 @@ public algorithm of a dependency whose source is not in the checkout, see SURVEY
 """
 import math
 
+import functools
+
 import numpy as np
 from scipy import signal
 from scipy.stats import norm
@@ -30,14 +32,24 @@ TAPER_FRACTION = 0.01          # helpers.py:139
 
 
 def design_bandpass(filter_type, fmin, fmax, order, ripple, fs):
-    """-> (sos applied to the data, zero_phase flag, sos returned to the caller)."""
+    """-> (sos applied to the data, zero_phase flag, sos returned to the caller).  The design itself is
+    cached (a band set is usually reused for many traces); the Nyquist warning is raised on every call."""
+    sos_apply, zero_phase, sos_ret, nyquist = _design_cached(filter_type, float(fmin), float(fmax), int(order),
+                                                             float(ripple), float(fs))
+    if nyquist:
+        import warnings
+        warnings.warn('Selected high corner frequency (%s) of bandpass is at or above Nyquist (%s). '
+                      'Applying a high-pass instead.' % (fmax, 0.5 * fs))
+    return sos_apply.copy(), zero_phase, sos_ret.copy()
+
+
+@functools.lru_cache(maxsize=4096)
+def _design_cached(filter_type, fmin, fmax, order, ripple, fs):
     if filter_type == 'butter':
         fe = 0.5 * fs
         low, high = fmin / fe, fmax / fe
-        if high - 1.0 > -1e-6:
-            import warnings
-            warnings.warn('Selected high corner frequency (%s) of bandpass is at or above Nyquist (%s). '
-                          'Applying a high-pass instead.' % (fmax, fe))
+        nyquist = high - 1.0 > -1e-6
+        if nyquist:
             z, p, k = signal.iirfilter(order, low, btype='highpass', ftype='butter', output='zpk')
         else:
             if low > 1:
@@ -45,11 +57,11 @@ def design_bandpass(filter_type, fmin, fmax, order, ripple, fs):
             z, p, k = signal.iirfilter(order, [low, high], btype='band', ftype='butter', output='zpk')
         sos_apply = signal.zpk2sos(z, p, k)
         sos_ret = signal.iirfilter(order, [fmin, fmax], btype='band', ftype='butter', fs=fs, output='sos')
-        return sos_apply, True, sos_ret
+        return sos_apply, True, sos_ret, nyquist
     if filter_type == 'cheby1':
         sos = signal.iirfilter(order, [fmin, fmax], rp=ripple, btype='band', analog=False,
                                ftype='cheby1', fs=fs, output='sos')
-        return sos, False, sos
+        return sos, False, sos, False
     raise ValueError('unknown FILTER_TYPE %r (expected "butter" or "cheby1")' % (filter_type,))
 
 
