@@ -21,16 +21,15 @@
 //
 // The result is the FP64 arg-max (up to FP64 rounding ties, as for any summation order) at a small
 // fraction of the FP64 work: the screening runs on the int8 matrix pipe, ~64x the FP64 MFMA rate per
-// instruction, x1/4 for the limb products.
+// instruction, x1/3 for the limb products.
 //
 // Tile mapping (as in xcorr_mfma_kernel): rows r = 16 consecutive lags, columns c = (partner j,
 // 16-lag block s), K = 64 samples per MFMA:
-//     A[r][k] = q_i[n' + k + r + D0]   (16 byte-shifted copies of the sliding channel in LDS, so that
-//                                       every lane's 16-byte fragment is an aligned ds_read_b128)
+//     A[r][k] = q_i[n' + k + r + D0]   (8 byte-shifted copies of the sliding channel in LDS: every lane's
+//                                       16-byte fragment is two aligned ds_read_b64 from copy r & 7)
 //     B[k][c] = q_j(c)[n' + k - 16 s(c)]
-// One workgroup per (unit, sliding channel i); its four waves share the tile steps; two tile steps are
-// processed together so that the B fragments are reused (LDS read bandwidth is the limiter: each
-// fragment pair feeds four MFMAs).
+// One workgroup per (unit, two sliding channels, partner group); four waves per sliding channel share
+// its lag groups; four tile steps are processed together so that the B fragments are reused.
 #include "nbls_internal.h"
 #include "wave_ops.h"
 #include <cstdlib>
