@@ -162,3 +162,26 @@ def test_confidence_intervals_against_brute_force(oracle):
     ev = np.linalg.eigvalsh(xij.T @ xij)
     cv, cb = confidence_intervals(xij, zz.T, np.array([1e-6]))
     assert cb[0] < 1e-3 and cv[0] < 1e-6
+
+
+def test_stdict_packing_matches_oracle(oracle):
+    """Vectorised dropped-element dictionary (engine.stdict_from_weights) against the oracle's loop:
+    same keys (str of the window time), same element lists, band prefix as the reference builds it."""
+    from narrow_band_least_squares_amd import engine
+    from narrow_band_least_squares_amd.narrow_band_least_squares import _band_prefix, _prefix_stdict
+    rng = np.random.default_rng(5)
+    xij, pair_idx, _ = planner.co_array(rng.standard_normal((2, 8)))
+    io = oracle.co_array(rng.standard_normal((2, 8)))[1]
+    assert np.array_equal(np.asarray(io), pair_idx)
+    for frac, nwin in ((0.0, 50), (0.07, 333), (0.6, 40), (1.0, 7)):
+        wts = (rng.random((nwin + 5, 28)) >= frac).astype(np.uint8)
+        t = 17884.0729166667 + np.arange(nwin + 5) * (15.0 / 86400) + rng.random(nwin + 5) * 1e-9
+        exp = oracle.stdict_from_weights(wts[:nwin].T, io, t[:nwin], 8)
+        got = engine.stdict_from_weights(wts, nwin, t, pair_idx, 8)
+        assert got.keys() == exp.keys() and got['size'] == 8
+        for k in exp:
+            if k != 'size':
+                np.testing.assert_array_equal(got[k], exp[k])
+        pre = engine.stdict_from_weights(wts, nwin, t, pair_idx, 8, prefix=_band_prefix(7))
+        ref = _prefix_stdict(exp, 7)
+        assert pre.keys() == ref.keys()
