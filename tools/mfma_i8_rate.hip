@@ -18,8 +18,10 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, int seed) {
 }
 int main() {
     int* d; hipMalloc(&d, 4096 * 256 * sizeof(int));
-    for (int wpb : {256, 512, 1024}) {
-        const int iters = 20000, blocks = 256 * (1024 / wpb) ;
+    // waves per SIMD: 1, 2, 4 (256-thread blocks = one wave per SIMD each), then 4 via bigger blocks
+    for (int cfg = 0; cfg < 5; ++cfg) {
+        const int wpb = cfg < 3 ? 256 : (cfg == 3 ? 512 : 1024);
+        const int iters = 20000, blocks = cfg < 3 ? 256 * (1 << cfg) : 256 * (1024 / wpb);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k, dim3(blocks), dim3(wpb), 0, 0, 100, d, 1);
         hipDeviceSynchronize();
