@@ -641,38 +641,32 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             // and only half of the A fragments are read from LDS per K step
             v4i a0h = ld_frag64(qa_h), a0l = ld_frag64(qa_l);
             v4i a1h = ld_frag64(qa_h + 32), a1l = ld_frag64(qa_l + 32);
-            v4i a2h, a2l, a3h, a3l, bhn, bln;
-// one K step: (C*) fragments in registers are consumed, (N*) fragments of the next step are fetched.
-// Order pinned with sched_barrier: all LDS reads first, then the six products of the fragments already
-// in registers (their 96 matrix-pipe cycles cover the LDS latency), then the six of the new ones.
-// Two steps with swapped roles per loop trip: no register-to-register copies.
-#define SCREEN_KSTEP(C0H, C0L, C1H, C1L, N0H, N0L, N1H, N1L, BH, BL, BHN, BLN)      \
-    {                                                                              \
-        const int nn = n0 + 64 < klen ? n0 + 64 : n0; /* the last step re-reads its own */ \
-        BHN = *(const v4i*)(pBh + nn);                                             \
-        BLN = *(const v4i*)(pBl + nn);                                             \
-        N0H = ld_frag64(qa_h + n0 + 64);                                           \
-        N0L = ld_frag64(qa_l + n0 + 64);                                           \
-        N1H = ld_frag64(qa_h + n0 + 96);                                           \
-        N1L = ld_frag64(qa_l + n0 + 96);                                           \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-        MFMA_I8(C0H, BH, h0); MFMA_I8(C0H, BL, m0);                                \
-        MFMA_I8(C1H, BH, h1); MFMA_I8(C1H, BL, m1);                                \
-        MFMA_I8(C0L, BH, m0); MFMA_I8(C1L, BH, m1);                                \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-        MFMA_I8(N0H, BH, h2); MFMA_I8(N0H, BL, m2);                                \
-        MFMA_I8(N1H, BH, h3); MFMA_I8(N1H, BL, m3);                                \
-        MFMA_I8(N0L, BH, m2); MFMA_I8(N1L, BH, m3);                                \
-        __builtin_amdgcn_sched_barrier(0);                                         \
-    }
-            for (int n0 = 0; n0 < klen;) {
-                SCREEN_KSTEP(a0h, a0l, a1h, a1l, a2h, a2l, a3h, a3l, bh, bl, bhn, bln)
-                n0 += 64;
-                if (n0 >= klen) break;
-                SCREEN_KSTEP(a2h, a2l, a3h, a3l, a0h, a0l, a1h, a1l, bhn, bln, bh, bl)
-                n0 += 64;
+            for (int n0 = 0; n0 < klen; n0 += 64) {
+                const int nn = n0 + 64 < klen ? n0 + 64 : n0;       // (the last step re-reads its own)
+                const v4i bhn = *(const v4i*)(pBh + nn);
+                const v4i bln = *(const v4i*)(pBl + nn);
+                const v4i a2h = ld_frag64(qa_h + n0 + 64);
+                const v4i a2l = ld_frag64(qa_l + n0 + 64);
+                const v4i a3h = ld_frag64(qa_h + n0 + 96);
+                const v4i a3l = ld_frag64(qa_l + n0 + 96);
+                // keep the order: all LDS reads first, then the six products of the fragments already in
+                // registers (their 96 matrix-pipe cycles cover the LDS latency), then the six of the new ones.
+                // (Unrolling by two with swapped roles removes the register copies below but pushes the
+                // kernel over 128 VGPRs: 100 B of scratch per lane = 1 GB of spill traffic per launch.)
+                __builtin_amdgcn_sched_barrier(0);
+                TILE_H(a0h, h0, m0);
+                TILE_H(a1h, h1, m1);
+                TILE_L(a0l, m0);
+                TILE_L(a1l, m1);
+                __builtin_amdgcn_sched_barrier(0);
+                TILE_H(a2h, h2, m2);
+                TILE_H(a3h, h3, m3);
+                TILE_L(a2l, m2);
+                TILE_L(a3l, m3);
+                __builtin_amdgcn_sched_barrier(0);
+                a0h = a2h; a0l = a2l; a1h = a3h; a1l = a3l;
+                bh = bhn; bl = bln;
             }
-#undef SCREEN_KSTEP
         } else
         for (int n0 = 0; n0 < klen; n0 += 64) {
             const int nn = n0 + 64 < klen ? n0 + 64 : n0;
