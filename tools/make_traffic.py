@@ -29,11 +29,15 @@ def pmc_means(d, counter):
 
 def main():
     tag, d = sys.argv[1], sys.argv[2]
+    traffic_only = len(sys.argv) > 3 and sys.argv[3] == '--traffic-only'
     out = d + '/out'
     import os
     os.makedirs(out, exist_ok=True)
-    shutil.copy(glob.glob(d + '/stats/*/*kernel_stats.csv')[0], '%s/%s_bench_cfg3_kernel_stats.csv' % (out, tag))
-    shutil.copy('%s/%s_bench_cfg3.json' % (d, tag), '%s/%s_bench_cfg3.json' % (out, tag))
+    if not traffic_only:
+        shutil.copy(glob.glob(d + '/stats/*/*kernel_stats.csv')[0], '%s/%s_bench_cfg3_kernel_stats.csv' % (out, tag))
+        shutil.copy('%s/%s_bench_cfg3.json' % (d, tag), '%s/%s_bench_cfg3.json' % (out, tag))
+        print(open('%s/%s_bench_cfg3.json' % (out, tag)).read().strip()[:600])
+        return
     fetch = pmc_means(d + '/fetch', 'FETCH_SIZE')
     write = pmc_means(d + '/write', 'WRITE_SIZE')
     for name, tab in (('fetch', fetch), ('write', write)):
@@ -54,7 +58,8 @@ def main():
                              'loads of this kernel are 16 B/lane); per-launch mean over the unit batches of a step',
                    'raw_per_launch_bytes': raw}}
     json.dump(js, open(out + '/traffic.json', 'w'), indent=1)
-    print(open('%s/%s_bench_cfg3.json' % (out, tag)).read().strip()[:600])
+    # bench.py reads profiles/traffic.json: refresh it BEFORE the bench run of this script
+    json.dump(js, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'traffic.json'), 'w'), indent=1)
     print('traffic per launch (%s): %.1f MB' % (dom, traffic / 1e6))
 
 
