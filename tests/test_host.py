@@ -185,3 +185,24 @@ def test_stdict_packing_matches_oracle(oracle):
         pre = engine.stdict_from_weights(wts, nwin, t, pair_idx, 8, prefix=_band_prefix(7))
         ref = _prefix_stdict(exp, 7)
         assert pre.keys() == ref.keys()
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """Register spills of the per-workgroup kernels turn into HBM traffic (an unrolled variant of the
+    screening kernel once wrote 1 GB of scratch per launch): the kernels of the cfg-3 path must compile
+    with private_segment_fixed_size == 0."""
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    csrc = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc')
+    want = {'xcorr_screen.hip': (['screen_kernel', 'quantize_reg_kernelILi4E', 'verify_lds_kernel'], []),
+            'solve.hip': (['solve_lts_wave_kernelILi28E', 'solve_ols_kernel'], ['-ffp-contract=off'])}
+    for src, (kernels, flags) in want.items():
+        out = tmp_path / (src + '.s')
+        subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + csrc, '-S', '--cuda-device-only',
+                        os.path.join(csrc, src), '-o', str(out)] + flags, check=True, stderr=subprocess.DEVNULL, timeout=600)
+        txt = out.read_text()
+        for k in kernels:
+            m = re.search(r'\.amdhsa_kernel \S*' + k + r'.*?\.amdhsa_private_segment_fixed_size (\d+)', txt, re.S)
+            assert m, k
+            assert int(m.group(1)) == 0, '%s spills %s bytes per lane' % (k, m.group(1))
