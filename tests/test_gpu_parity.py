@@ -434,3 +434,22 @@ def test_full_size_cfg3_properties():
     for j, i in enumerate(sub):
         for k in ('vel', 'baz', 'mdccm', 'weights'):
             np.testing.assert_array_equal(getattr(r3, k)[j], getattr(r1, k)[i])
+
+
+def test_full_size_cfg3_band_against_oracle(oracle):
+    """One whole band of BASELINE configs[2] (the lowest, 0.100-0.110 Hz: broadest correlation peaks, most
+    screening candidates; 1438 windows, 6 h @ 40 Hz) taken from the 48-band production run, against the
+    oracle: lags and LTS weights exact, vel / baz / MdCCM to 1e-9."""
+    c = _cfg('cfg3', 1.0)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    edges = [(c['freqlist'][i], c['freqlist'][i + 1]) for i in range(c['NBANDS'])]
+    res = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], 0.5, 0.5, 'butter', 2, 0.01, want_lag=True)
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', edges[0][0], edges[0][1], 2, 0.01)
+    out_o, internals = oracle.ltsva(stf_o, None, None, 30.0, 0.5, 0.5, rij=c['rij'], return_internals=True)
+    n = int(res.nwin[0])
+    assert n == len(out_o[0]) == 1438
+    np.testing.assert_array_equal(res.lag[0, :n], np.rint(internals['tau'].T * fs).astype(int))
+    np.testing.assert_array_equal(res.weights[0, :n], internals['weights'].T)
+    np.testing.assert_allclose(res.vel[0, :n], out_o[0], rtol=RTOL)
+    np.testing.assert_allclose(res.baz[0, :n], out_o[1], rtol=RTOL)
+    np.testing.assert_allclose(res.mdccm[0, :n], out_o[3], rtol=1e-9)
