@@ -144,10 +144,24 @@ def test_ltsva_parity(oracle, alpha):
     assert np.isfinite(cv).all()
 
 
-def test_ltsva_eight_elements_lts(oracle):
-    c = _cfg('cfg3', 0.02)     # 8 elements, 28 pairs, 378 starts
+@pytest.mark.parametrize('alpha', [0.5, 0.55, 0.9])
+def test_ltsva_eight_elements_lts(oracle, alpha):
+    c = _cfg('cfg3', 0.02)     # 8 elements, 28 pairs, 378 starts; h = 15, 16, 26
     stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 1.0, 4.0, 2, 0.01)
-    _compare_ltsva(oracle, c, stf_o, 30.0, 0.5)
+    _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
+
+
+@pytest.mark.parametrize('nchans,alpha', [(4, 0.5), (5, 0.6), (6, 0.9), (7, 0.5)])
+def test_ltsva_small_arrays_register_kernel(oracle, nchans, alpha):
+    """4..7 elements (6, 10, 15, 21 pairs): every instantiation of the register-resident LTS kernel (its own
+    sorting network each) against the oracle."""
+    fs, npts = 20.0, 4000
+    rij = synthetic.array_geometry(nchans, 1.0, seed=40 + nchans)
+    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=nchans - 1, seed=21 + nchans)
+    st = synthetic.make_stream(data, fs)
+    c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=st)
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 4.0, 2, 0.01)
+    _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
 
 
 @pytest.mark.parametrize('alpha,nine', [(0.5, False), (0.75, False), (0.5, True)])
@@ -273,7 +287,7 @@ def test_kernel_variants_agree(monkeypatch):
 
 
 @pytest.mark.parametrize('nchans,winlen', [(3, 20.0), (4, 12.5), (5, 30.0), (7, 9.0), (9, 25.0), (12, 15.0), (16, 40.0),
-                                           (17, 10.0), (20, 12.0), (32, 15.0)])
+                                           (17, 10.0), (20, 12.0), (32, 15.0), (6, 12.525), (8, 12.175), (8, 51.3)])
 def test_correlators_agree_for_any_array_size(nchans, winlen):
     """Tile geometry depends on the element count (lag blocks per tile, partner skew, idle columns):
     the int8-screening and f64-MFMA correlators must pick the lags of the plain VALU kernel for every
