@@ -27,6 +27,7 @@
 // 2 reads + 1 write of 8 B per sample per pass.
 #include "nbls_internal.h"
 #include "wave_ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -92,6 +93,75 @@ __global__ __launch_bounds__(256) void filter_state_kernel(FilterArgs a) {
         double* st = a.cstate + (chunk * a.nseries + q) * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) st[d] = acc[d];
+    }
+}
+
+// ---- states on the FP64 matrix cores (forward pass, D = 2, 4, 8 or 16) ----
+// e[(band, d)][chunk] = sum_t w[(band, d)][t] x[chunk][t] is a GEMM with M = B*D rows (weights), N = all
+// chunks of all channels, K = C samples.  A workgroup owns one tile of 16 rows (its weights are staged once
+// in LDS, row stride C + 4 doubles: conflict-free fragment reads) and walks column tiles of 16 consecutive
+// chunks of one channel with v_mfma_f64_16x16x4_f64 (A[i][k]: lane i + 16k, B[k][j]: lane j + 16k,
+// D[i][j]: lane j + 16 (i % 4), register i / 4).  The trace is read straight from L2 (each 32-byte piece
+// of a chunk row serves four K steps through L1); the weights are read once per workgroup.
+typedef double d4f __attribute__((ext_vector_type(4)));
+
+template <int S>
+__global__ __launch_bounds__(256) void filter_state_mfma_kernel(FilterArgs a, int nbands) {
+    constexpr int D = 2 * S;
+    constexpr int P = C + 4;
+    extern __shared__ double wts[];                 // [16][P]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row0 = blockIdx.x * 16;               // first (band, d) row of this workgroup
+    for (int idx = tid; idx < 16 * C; idx += 256) {
+        const int r = idx / C, t = idx % C;
+        const int grow = row0 + r, band = grow / D, d = grow % D;
+        wts[r * P + t] = band < nbands ? a.fw[((int64_t)band * C + t) * D + d] : 0.0;
+    }
+    __syncthreads();
+    const int tpc = (int)((a.nchunks + 15) / 16);   // column tiles per channel
+    const int ntile = a.nchans * tpc;
+    const int i = lane & 15, k = lane >> 4;
+    // The sum over the samples may run in any order as long as both operands agree on it: K slot k of
+    // step (m, u) stands for sample 16 m + 4 k + u, so that a lane fetches 32 contiguous bytes of its
+    // chunk per four steps (whole 128-byte lines per wave) instead of 8 bytes per step.
+    const double* wrow = wts + i * P + 4 * k;
+    for (int ct = blockIdx.y * 4 + wv; ct < ntile; ct += gridDim.y * 4) {
+        const int ch = ct / tpc;
+        const int64_t chunk = (int64_t)(ct % tpc) * 16 + i;          // this lane's column (B operand)
+        const double* x = a.in + (int64_t)ch * a.in_stride + chunk * C + 4 * k;
+        const int64_t left = chunk < a.nchunks ? a.npts - (chunk * C + 4 * k) : 0;   // valid samples from x[0]
+        d4f acc = {0.0, 0.0, 0.0, 0.0};
+        auto fetch = [&](int m, double (&v)[4]) {
+            const int64_t off = 16 * m;
+            if (off + 4 <= left) {
+                const double2 p0 = *(const double2*)(x + off), p1 = *(const double2*)(x + off + 2);
+                v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = off + u < left ? x[off + u] : 0.0;
+            }
+        };
+        double cur[4], nxt[4];
+        fetch(0, cur);
+        for (int m = 0; m < C / 16; ++m) {
+            if (m + 1 < C / 16) fetch(m + 1, nxt);                  // in flight during this block's four products
+            const double2 w0 = *(const double2*)(wrow + 16 * m), w1 = *(const double2*)(wrow + 16 * m + 2);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0.x, cur[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0.y, cur[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1.x, cur[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1.y, cur[3], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int grow = row0 + 4 * r + k;       // D row = 4 * register + (lane >> 4)
+            const int band = grow / D, d = grow % D;
+            if (band < nbands && chunk < a.nchunks) {
+                const int q = band * a.nchans + ch;
+                a.cstate[(chunk * a.nseries + q) * D + d] = acc[r];
+            }
+        }
     }
 }
 
@@ -298,7 +368,22 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
 
 template <int S>
 hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
-    if (!states_ready)
+    constexpr int D = 2 * S;
+    static const bool no_mfma = getenv("NBLS_FILTER_NOMFMA") != nullptr;   // developer: VALU state kernel
+    if (!states_ready && !a.reverse && (16 % D) == 0 && a.in_mod == a.nchans && !no_mfma) {
+        const int nbands = a.nseries / a.nchans;
+        const int rows = (nbands * D + 15) / 16;
+        const size_t shm = (size_t)16 * (C + 4) * sizeof(double);
+        hipError_t e = hipFuncSetAttribute((const void*)filter_state_mfma_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        const int tiles = a.nchans * (int)((a.nchunks + 15) / 16);
+        // column tiles per wave chosen so that the grid is about one round of two workgroups per CU
+        int per_wave = (rows * tiles + 4 * 512 - 1) / (4 * 512);
+        if (per_wave < 1) per_wave = 1;
+        int splits = (tiles + 4 * per_wave - 1) / (4 * per_wave);
+        if (splits < 1) splits = 1;
+        hipLaunchKernelGGL((filter_state_mfma_kernel<S>), dim3((unsigned)rows, (unsigned)splits), dim3(256), shm, h->stream, a, nbands);
+    } else if (!states_ready)
         hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nseries),
                            dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nseries + 63) / 64, a.ngroups), dim3(64), 0,
