@@ -364,7 +364,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         size_t lds_;
         (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
         // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
-        int64_t batch = (int64_t)(96ll << 20) / ((int64_t)h->nchans * 2 * WP_);
+        int64_t batch_mb = 96;
+        { const char* be = getenv("NBLS_SCREEN_BATCH_MB"); if (be && atoi(be) > 0) batch_mb = atoi(be); }   // developer
+        int64_t batch = (int64_t)(batch_mb << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
         if (batch > U) batch = U > 0 ? U : 1;
         h->screen_batch = batch;
