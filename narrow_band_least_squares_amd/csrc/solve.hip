@@ -625,7 +625,7 @@ __device__ inline void subset_le(const double (&a)[PT], double T, unsigned int& 
     (one(std::integral_constant<int, K>{}), ...);
 }
 
-template <int PT>
+template <int PT, int H = 0>     // H: the plan's h when it is known at compile time (0 = run-time h)
 __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* X0, const double* X1, int h,
                                         double z0, double z1) {
     using Seq = std::make_integer_sequence<int, PT>;
@@ -646,8 +646,10 @@ __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* 
         double v[PT];
         copy_reg<PT>(v, a, Seq{});
         SortNet<PT>::run(v);
-        double T = v[PT - 1];
-        pick_sorted<PT>(v, h, T, Seq{});
+        // with h fixed at compile time only the comparators that feed output h-1 survive (P = 28,
+        // h = 15: 235 of the 324 min/max instructions) and there is no run-time pick
+        double T = v[H > 0 ? H - 1 : PT - 1];
+        if (H == 0) pick_sorted<PT>(v, h, T, Seq{});
         unsigned int m = 0u;
         int cnt = 0;
         double obj = 0.0;
@@ -736,7 +738,7 @@ __device__ inline double wave_nanmedian(const double* v, int P, double* srt, int
 // FAST-LTS with ONE WAVE PER UNIT: the starts are swept in rounds of 64 lanes, the candidate
 // peel-off / refinement / finish stay inside the wave (shuffles + the wave's own LDS slab), so
 // there is no workgroup barrier and no idle wave during the serial tail.
-template <int PT>
+template <int PT, int H>
 __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nunits, int slab_doubles) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     constexpr int P = PT;
     const int S = a.nstarts;
-    const int h = a.h;
+    const int h = H > 0 ? H : a.h;
     const int64_t o = (int64_t)band * a.vector_len + w;
 
     const int wave_id = blockIdx.x * 4 + wv;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
             } else {
                 fit_reg<PT>(txx, txy, tyy, tbx, tby, sm_, &z0, &z1);
             }
-            const RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
+            const RegSel<PT> sel = select_reg<PT, H>(y, X0, X1, h, z0, z1);
             maskS[s] = sel.mask;
             prevS[s] = 0.0;
             stt[s] = sel.ok ? 1 : 0;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
                 const double prev = prevS[id];
                 double n0, n1;
                 fit_reg<PT>(txx, txy, tyy, tbx, tby, mk, &n0, &n1);
-                const RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, n0, n1);
+                const RegSel<PT> sel = select_reg<PT, H>(y, X0, X1, h, n0, n1);
                 if (!sel.ok) {
                     stt[id] = 0;
                 } else if ((kk >= 1 && sel.obj == prev) || kk == a.csteps - 1) {
@@ -1016,14 +1018,14 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
     if (stp) stp[4] = __builtin_amdgcn_s_memtime();
     if (lane < nc) {
         double z0 = z0S[cand[lane]], z1 = z1S[cand[lane]];
-        RegSel<PT> sel = select_reg<PT>(y, X0, X1, h, z0, z1);
+        RegSel<PT> sel = select_reg<PT, H>(y, X0, X1, h, z0, z1);
         double pobj = 0.0, cobj = __builtin_inf();
         if (!sel.ok) cobj = dnan();
         else {
             for (int kk = 0; kk < a.csteps2; ++kk) {
                 double n0, n1;
                 fit_reg<PT>(txx, txy, tyy, tbx, tby, sel.mask, &n0, &n1);
-                sel = select_reg<PT>(y, X0, X1, h, n0, n1);
+                sel = select_reg<PT, H>(y, X0, X1, h, n0, n1);
                 z0 = n0;
                 z1 = n1;
                 if (!sel.ok) { cobj = dnan(); break; }
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
             const int k = lane < P ? lane : 0;
             const double tk = tauv[k], c0 = x0[k], c1 = x1[k];
             const unsigned long long pmask = (P < 64) ? ((1ull << P) - 1ull) : ~0ull;
-            RegSel<PT> sel = select_reg<PT>(tauv, x0, x1, h, zr0, zr1);
+            RegSel<PT> sel = select_reg<PT, H>(tauv, x0, x1, h, zr0, zr1);
             const double s0 = sqrt(sel.obj / (double)h) * a.raw_factor;
             double zf0 = zr0, zf1 = zr1;
             const double rk0 = (tk - c0 * zr0) - c1 * zr1;
@@ -1120,18 +1122,27 @@ int lts_wave_slab_doubles(int P, int S) {
     return (int)(b / sizeof(double));
 }
 
-template <int PT>
-hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
+template <int PT, int H>
+hipError_t launch_fast_h(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
     int slab = lts_wave_slab_doubles(PT, a.nstarts);
     { const char* e = getenv("NBLS_LTS_PAD_KB"); if (e) slab += atoi(e) * 128; }   // occupancy experiment
     const size_t shm = (size_t)slab * 4 * sizeof(double);
     if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)solve_lts_wave_kernel<PT>,
+        hipError_t e = hipFuncSetAttribute((const void*)solve_lts_wave_kernel<PT, H>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((solve_lts_wave_kernel<PT>), dim3((nunits + 3) / 4), dim3(256), shm, st, a, nunits, slab);
+    hipLaunchKernelGGL((solve_lts_wave_kernel<PT, H>), dim3((nunits + 3) / 4), dim3(256), shm, st, a, nunits, slab);
     return hipGetLastError();
+}
+
+// HALF = h of alpha = 0.5 for this pair count (the default LTS setting): its own instantiation with the
+// selection network pruned to that output; every other h runs the generic one.
+template <int PT, int HALF>
+hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
+    static const bool generic_only = getenv("NBLS_LTS_GENERIC_H") != nullptr;   // developer
+    if (a.h == HALF && !generic_only) return launch_fast_h<PT, HALF>(h, a, nunits, st);
+    return launch_fast_h<PT, 0>(h, a, nunits, st);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1674,11 +1685,11 @@ hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     }
     if (h->lts_impl != 1) {
         switch (h->npairs) {     // register-resident kernel for 4..8 elements (larger P spills registers)
-            case 6: return launch_fast<6>(h, a, nunits, st);
-            case 10: return launch_fast<10>(h, a, nunits, st);
-            case 15: return launch_fast<15>(h, a, nunits, st);
-            case 21: return launch_fast<21>(h, a, nunits, st);
-            case 28: return launch_fast<28>(h, a, nunits, st);
+            case 6: return launch_fast<6, 4>(h, a, nunits, st);
+            case 10: return launch_fast<10, 6>(h, a, nunits, st);
+            case 15: return launch_fast<15, 9>(h, a, nunits, st);
+            case 21: return launch_fast<21, 12>(h, a, nunits, st);
+            case 28: return launch_fast<28, 15>(h, a, nunits, st);
             default: break;
         }
     }
