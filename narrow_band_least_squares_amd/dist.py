@@ -104,7 +104,19 @@ def all_gather_device_grids(ptrs, nbytes, shape, device_index=0):
         per = [all_gather_device_grid(p, shape, np.float64, device_index) for p in ptrs[:4]]
         return [np.stack([per[g][r] for g in range(4)]) for r in range(world)]
     t = torch.as_tensor(_DevArray(ptrs[0], (4 * cells,), np.dtype(np.float64).str), device='cuda:%d' % device_index)
-    out = torch.empty((world, 4 * cells), dtype=torch.float64, device=t.device)
+    key = (world, 4 * cells, device_index)
+    bufs = _GATHER_BUFFERS.get(key)
+    if bufs is None:        # device destination + pinned host landing zone, reused by every call of this shape
+        bufs = (torch.empty((world, 4 * cells), dtype=torch.float64, device=t.device),
+                torch.empty((world, 4 * cells), dtype=torch.float64, pin_memory=True))
+        _GATHER_BUFFERS.clear()
+        _GATHER_BUFFERS[key] = bufs
+    out, pinned = bufs
     td.all_gather_into_tensor(out, t)
-    host = out.cpu().numpy()
-    return [host[r].reshape((4,) + tuple(shape)) for r in range(world)]
+    pinned.copy_(out, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    host = pinned.numpy()
+    return [host[r].reshape((4,) + tuple(shape)).copy() for r in range(world)]
+
+
+_GATHER_BUFFERS = {}
