@@ -467,3 +467,36 @@ def test_full_size_cfg3_band_against_oracle(oracle):
     np.testing.assert_allclose(res.vel[0, :n], out_o[0], rtol=RTOL)
     np.testing.assert_allclose(res.baz[0, :n], out_o[1], rtol=RTOL)
     np.testing.assert_allclose(res.mdccm[0, :n], out_o[3], rtol=1e-9)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_configurations_against_oracle(oracle, seed):
+    """Seeded random draws over what the drop-in call accepts: 4..9 elements, sampling rate, band type and
+    count, window length (constant or adaptive), overlap, OLS or LTS with a random alpha, filter type and
+    order, SNR, with or without a mistimed element — the whole 9-tuple against the oracle."""
+    from narrow_band_least_squares_amd import helpers
+    rng = np.random.default_rng(1000 + seed)
+    nchans = int(rng.integers(4, 10))
+    fs = float(rng.choice([20.0, 40.0, 50.0]))
+    dur = float(rng.uniform(300.0, 700.0))
+    npts = int(dur * fs) + int(rng.integers(0, 7))
+    band_type = str(rng.choice(['linear', 'log', 'octave', '2_octave_over', 'onethird_octave']))
+    fmin, fmax = float(rng.uniform(0.2, 0.6)), float(rng.uniform(3.0, 0.4 * fs))
+    nb = int(rng.integers(2, 7))
+    freqlist, nbands, _ = helpers.get_freqlist(fmin, fmax, band_type, nb)
+    if rng.random() < 0.5:
+        winlens = helpers.get_winlenlist('constant', nbands, 50, float(rng.choice([20.0, 30.0, 45.0])), 0)
+    else:
+        winlens = helpers.get_winlenlist('adaptive', nbands, 50, 60, 25)
+    alpha = 1.0 if rng.random() < 0.35 else float(rng.choice([0.5, 0.6, 0.75, 0.9]))
+    ftype = 'butter' if rng.random() < 0.6 else 'cheby1'
+    bad = nchans - 1 if (alpha < 1.0 and rng.random() < 0.7) else None
+    rij = synthetic.array_geometry(nchans, float(rng.uniform(0.5, 2.0)), seed=int(rng.integers(1 << 30)))
+    data = synthetic.plane_wave(rij, npts, fs, fmin, min(fmax, 0.45 * fs), baz_deg=float(rng.uniform(0, 360)),
+                                vel_kms=float(rng.uniform(0.3, 3.0)), snr_db=float(rng.uniform(-3, 12)),
+                                timing_error_s=0.3 if bad is not None else 0.0, bad_element=bad,
+                                seed=int(rng.integers(1 << 30)))
+    c = dict(WINLEN_list=winlens, overlap=float(rng.choice([0.0, 0.25, 0.5, 0.75])), alpha=alpha,
+             st=synthetic.make_stream(data, fs), NBANDS=nbands, freqlist=freqlist, band_type=band_type, ftype=ftype,
+             order=int(rng.integers(1, 4)), ripple=0.01, rij=rij - rij.mean(axis=1, keepdims=True), data=data, fs=fs)
+    _compare_nbls(oracle, c, np.logspace(-2, 1, 40))
