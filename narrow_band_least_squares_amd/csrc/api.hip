@@ -148,7 +148,7 @@ void nbls_destroy(nbls_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
-                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_filt, h->d_cstate, h->d_cstate2,
+                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2,
                     h->d_lag, h->d_cmax, h->d_vel /* + baz, mdccm, sigma_tau */, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -315,6 +315,12 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     for (int b = 0; b < nbands; ++b)
         for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) ub[(size_t)u] = b;
     if ((rc = alloc_copy(h, &h->d_unit_band, ub.data(), (size_t)U))) return rc;
+    {
+        std::vector<int32_t> uw((size_t)(U > 0 ? U : 1));
+        for (int b = 0; b < nbands; ++b)
+            for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) uw[(size_t)u] = (int32_t)(u - h->unit_off[b]) + woff[b];
+        if ((rc = alloc_copy(h, &h->d_unit_win, uw.data(), (size_t)U))) return rc;
+    }
 
     const size_t nseries = (size_t)nbands * h->nchans;
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;

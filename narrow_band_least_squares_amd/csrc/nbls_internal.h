@@ -60,6 +60,7 @@ struct nbls_handle {
     int32_t* d_win_off = nullptr;  // [B] first window processed per band
     std::vector<int32_t> win_first, win_count;   // optional per-band window ranges (nbls_set_window_ranges)
     int32_t* d_unit_band = nullptr;// [U]
+    int32_t* d_unit_win = nullptr; // [U] window index (global, inside the band) of every unit: saves the kernels a dependent load
 
     // ---- work + results ----
     double* d_filt = nullptr;      // [B][N][npts_pad]

@@ -35,6 +35,7 @@ struct SArgs {
     const int32_t* unit_off;
     const int32_t* win_off;   // [B] first window of each band's range (window sharding)
     const int32_t* unit_band;
+    const int32_t* unit_win;  // [U] window index of every unit
     double fs;
     const double* xij;     // [P][2]
     const double* xpinv;   // [2][P]
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
     const int u = a.u0 + blockIdx.x * 4 + wv;
     if (u >= a.u0 + nunits) return;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
+    const int w = a.unit_win[u];                            // window index inside the band (global)
     constexpr int P = PT;
     const int S = a.nstarts;
     const int h = H > 0 ? H : a.h;
@@ -1645,6 +1646,7 @@ hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.unit_off = h->d_unit_off;
     a.win_off = h->d_win_off;
     a.unit_band = h->d_unit_band;
+    a.unit_win = h->d_unit_win;
     a.fs = h->fs;
     a.xij = h->d_xij;
     a.xpinv = h->d_xpinv;

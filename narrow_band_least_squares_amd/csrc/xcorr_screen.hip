@@ -54,6 +54,7 @@ struct QArgs {
     const int32_t* unit_off;
     const int32_t* win_off;   // [B] first window of each band's range (window sharding)
     const int32_t* unit_band;
+    const int32_t* unit_win;  // [U] window index of every unit (= u - unit_off[band] + win_off[band])
     int u0, nu;               // unit batch
     int WP;                   // padded window bytes (multiple of 16)
     int8_t* qbuf;             // [nu][N][2][WP]
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
     const int ul = item / N, ch = item % N;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
+    const int w = a.unit_win[u];                            // window index inside the band (global)
     const int W = a.Wb[band];
     const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + (int64_t)w * a.incb[band];
     const int ng8 = a.WP / 8;
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     const int ul = blockIdx.x;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
+    const int w = a.unit_win[u];                            // window index inside the band (global)
     const int W = a.Wb[band];
     const int64_t t0 = (int64_t)w * a.incb[band];
     // issue the candidate-record and norm loads of this wave's pairs first: their latency hides
@@ -1057,6 +1058,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.unit_off = h->d_unit_off;
     a.win_off = h->d_win_off;
     a.unit_band = h->d_unit_band;
+    a.unit_win = h->d_unit_win;
     a.qbuf = h->d_qbuf;
     a.qmeta = h->d_qmeta;
     a.qms = 4 + a.WP / 32 + 4;                     // ss, L1, max, 0, cum[WP/32 + 2], sum lo^2, pad
