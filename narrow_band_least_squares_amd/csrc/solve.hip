@@ -1359,7 +1359,7 @@ __device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int ma
     }
 }
 
-__global__ __launch_bounds__(512) void solve_lts_coop_kernel(SArgs a, int nunits) {
+__global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunits) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -1701,7 +1701,9 @@ hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipSt
         if (cshm <= 160 * 1024 && h->npairs <= 512) {
             hipError_t ce = hipFuncSetAttribute((const void*)solve_lts_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
             if (ce != hipSuccess) return ce;
-            const int threads = a.nstarts > 256 ? 512 : 256;
+            int threads = a.nstarts > 256 ? 512 : 256;
+            if (cshm > 80 * 1024 && a.nstarts > 512 - 64) threads = 1024;    // one workgroup per CU anyway: give it all four wave slots per SIMD
+            { const char* te = getenv("NBLS_LTS_COOP_THREADS"); if (te && atoi(te) >= 64) threads = atoi(te); }   // developer
             hipLaunchKernelGGL(solve_lts_coop_kernel, dim3(nunits), dim3(threads), cshm, st, a, nunits);
             return hipGetLastError();
         }

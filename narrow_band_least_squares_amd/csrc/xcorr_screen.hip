@@ -65,6 +65,7 @@ struct QArgs {
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
     int npg;                  // partner groups per sliding channel (1 up to 17 elements)
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
+    int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         }
     }
     // energy-table entry of this thread (f32 tables for the lag-block pruning): fetched now, stored after the images
-    const bool tab_on = tid < (NSL + N) * (NB + 1);
+    const bool tab_on = a.tab_lds && tid < (NSL + N) * (NB + 1);
     const int tab_row = tab_on ? tid / (NB + 1) : 0, tab_k = tab_on ? tid - tab_row * (NB + 1) : 0;
     double tab_a = 0.0, tab_b = 0.0;
     if (tab_on) {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         if (tab_row < NSL) tailT[tab_row * (NB + 1) + tab_k] = __double2float_ru(tab_a - tab_b);
         else cumT[(tab_row - NSL) * (NB + 1) + tab_k] = __double2float_ru(tab_b);
     }
-    for (int idx = tid + nthr; idx < (NSL + N) * (NB + 1); idx += nthr) {      // (more than nthr entries: big arrays)
+    for (int idx = tid + nthr; a.tab_lds && idx < (NSL + N) * (NB + 1); idx += nthr) {      // (more than nthr entries: big arrays)
         const int row = idx / (NB + 1), k = idx - row * (NB + 1);
         if (row < NSL) {
             const int chs = NSL * cp + row;
@@ -571,7 +572,6 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // energy tables of the two channels of this lane's column (see quantize_kernel)
     const double* cum_i = mi + 4;
     const double* cum_j = mj + 4;
-    (void)cum_i; (void)cum_j;
 
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
 // 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
@@ -622,7 +622,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
                 const int kp = (W - D0 + 31) / 32 < NB ? (W - D0 + 31) / 32 : NB;
-                const float bound = sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f;
+                const float bound = a.tab_lds ? sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f
+                                              : (float)(sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]) * (1.0 + 1e-6));
                 const float gm = ord2f(gmaxh[jj]);
                 prunable = bound * 1.000001f + (float)(1.0e-6 * iabs) < gm - theta;
             }
@@ -1033,12 +1034,12 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     *CSA = csa;
     // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
     // LDS, else one sliding channel (4 waves, N-1 images)
-    // + running maxima and merge scalars (6 x 32 ints) + the f32 energy tables of the pruning test
-    const int NBt = *WP / 32 + 2;
-    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + (size_t)(2 + N) * NBt * 4 + 64;
-    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + (size_t)(1 + N) * NBt * 4 + 64;
+    // + running maxima and merge scalars (6 x 32 ints); the f32 energy tables of the pruning test are added by
+    // the caller when they still fit (nbls_screen_tables)
+    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 64;
+    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 64;
     static const bool force1 = getenv("NBLS_SCREEN_NSL1") != nullptr;    // developer: one sliding channel per workgroup
-    if (lds2 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
+    if (lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
 }
@@ -1050,6 +1051,12 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     const int N = h->nchans;
     a.npg = (N - 1 + 15) / 16;
     a.Wuni = h->uniW;
+    {   // energy tables in LDS when they do not cost occupancy (two workgroups per CU, or still one)
+        const size_t tab = (size_t)(a.nsl + N) * (a.WP / 32 + 2) * 4;
+        const size_t cap = lds <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+        a.tab_lds = lds + tab <= cap ? 1 : 0;
+        if (a.tab_lds) lds += tab;
+    }
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
     a.nchans = N;

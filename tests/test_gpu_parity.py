@@ -500,3 +500,22 @@ def test_random_configurations_against_oracle(oracle, seed):
              st=synthetic.make_stream(data, fs), NBANDS=nbands, freqlist=freqlist, band_type=band_type, ftype=ftype,
              order=int(rng.integers(1, 4)), ripple=0.01, rij=rij - rij.mean(axis=1, keepdims=True), data=data, fs=fs)
     _compare_nbls(oracle, c, np.logspace(-2, 1, 40))
+
+
+def test_cfg4_window_shape_keeps_the_screening_correlator():
+    """BASELINE configs[3] shape (16 elements, 30 s windows at 100 Hz = 3000 samples): the automatic
+    choice must still be the int8 screening correlator (its LDS budget is tight there), with the lags of
+    the plain VALU kernel."""
+    rij = synthetic.array_geometry(16, 2.0, seed=5)
+    data = synthetic.plane_wave(rij, 9000, 100.0, 0.5, 10.0, seed=6)
+    kw = dict(want_lag=True, want_cmax=True)
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        got = engine.process(data, 100.0, 0.0, rij, [(0.5, 5.0)], [30.0], 0.5, 1.0, 'butter', 2, 0.01, **kw)
+        assert h.timings()['xcorr_impl'] == 3
+    finally:
+        h.set_profiling(False)
+    ref = engine.process(data, 100.0, 0.0, rij, [(0.5, 5.0)], [30.0], 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=1, **kw)
+    np.testing.assert_array_equal(got.lag, ref.lag)
+    np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
