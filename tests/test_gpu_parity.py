@@ -502,6 +502,21 @@ def test_random_configurations_against_oracle(oracle, seed):
     _compare_nbls(oracle, c, np.logspace(-2, 1, 40))
 
 
+@pytest.mark.parametrize('nchans,fs,winlen', [(6, 20.0, 30.0), (8, 20.0, 60.0), (8, 40.0, 30.0), (32, 20.0, 30.0)])
+def test_baseline_shapes_use_the_screening_correlator(nchans, fs, winlen):
+    """Array size x window length of every BASELINE configuration (cfg-4 has its own test below): the
+    automatic choice is the int8 screening correlator (a fallback to the VALU kernel is 50x slower)."""
+    rij = synthetic.array_geometry(nchans, 1.0, seed=nchans)
+    data = synthetic.plane_wave(rij, int(2.6 * winlen * fs), fs, 0.5, 0.4 * fs, seed=3)
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        engine.process(data, fs, 0.0, rij, [(0.5, 4.0)], [winlen], 0.5, 1.0, 'butter', 2, 0.01)
+        assert h.timings()['xcorr_impl'] == 3
+    finally:
+        h.set_profiling(False)
+
+
 def test_cfg4_window_shape_keeps_the_screening_correlator():
     """BASELINE configs[3] shape (16 elements, 30 s windows at 100 Hz = 3000 samples): the automatic
     choice must still be the int8 screening correlator (its LDS budget is tight there), with the lags of
