@@ -102,6 +102,19 @@ def test_filter_data_parity(oracle, ftype, fmin, fmax):
     np.testing.assert_array_equal(c['st'][0].data, c['data'][0])
 
 
+@pytest.mark.parametrize('ftype,order', [('butter', 1), ('butter', 3), ('butter', 4), ('cheby1', 5), ('butter', 8)])
+def test_filter_orders_cover_every_state_kernel(oracle, ftype, order):
+    """1..8 second-order sections: state sizes 2, 8 and 16 take the matrix-core state kernel, 6 and 10 the
+    VALU one; zero-phase (butter) fuses the backward states into the forward apply."""
+    c = _cfg('cfg2', 0.3)
+    stf, fs, sos = filter_data(c['st'], ftype, 0.8, 3.0, order, 0.01)
+    stf_o, _, sos_o = oracle.filter_data(_ostream(oracle, c), ftype, 0.8, 3.0, order, 0.01)
+    np.testing.assert_array_equal(sos, sos_o)
+    scale = max(np.abs(tr.data).max() for tr in stf_o)
+    for a, b in zip(stf, stf_o):
+        assert np.max(np.abs(a.data - b.data)) <= 1e-11 * scale
+
+
 def _compare_ltsva(oracle, c, stf_o, winlen, alpha):
     out_o, internals = oracle.ltsva(stf_o, None, None, winlen, 0.5, alpha, rij=c['rij'], return_internals=True)
     data = np.array([tr.data for tr in stf_o])
