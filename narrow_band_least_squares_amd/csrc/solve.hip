@@ -1215,8 +1215,22 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
     }
     // h-th smallest key, high word first (31 passes of 32-bit compares); the low word needs its own
     // bisection only if several keys share the winning high word (rare for residuals)
-    unsigned int Thi = 0u;
-    for (int b = 30; b >= 0; --b) {
+    // the high words share their leading bits (sign 0, the top of the exponent): the bisection starts
+    // below the highest bit in which the smallest and the largest differ
+    unsigned int hmin = ~0u, hmax = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < PW && lane + 64 * i < P) {
+            const unsigned int hw = (unsigned int)(key[i] >> 32);
+            hmin = hw < hmin ? hw : hmin;
+            hmax = hw > hmax ? hw : hmax;
+        }
+    hmin = nbls_wave::min_u32(hmin);
+    hmax = nbls_wave::max_u32(hmax);
+    const unsigned int hdiff = hmin ^ hmax;
+    const int btop = hdiff ? 31 - __builtin_clz(hdiff) : -1;       // wave-uniform
+    unsigned int Thi = btop >= 31 ? 0u : (btop < 0 ? hmin : (hmin & ~((2u << btop) - 1u)));
+    for (int b = btop > 30 ? 30 : btop; b >= 0; --b) {
         const unsigned int cnd = Thi | (1u << b);
         int cnt = 0;
 #pragma unroll

@@ -30,4 +30,27 @@ __device__ inline double min_f64(double v) {       // NaN lanes are ignored (fmi
     return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+template <int CTRL>
+__device__ inline unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ inline unsigned int min_u32(unsigned int v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ inline unsigned int max_u32(unsigned int v) {
+    v = max(v, dpp_u32<0xB1>(v));
+    v = max(v, dpp_u32<0x4E>(v));
+    v = max(v, dpp_u32<0x141>(v));
+    v = max(v, dpp_u32<0x140>(v));
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
 }  // namespace nbls_wave
