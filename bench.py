@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: (window x band) LTS solves/s on the 8-element synthetic configuration
-(BASELINE.json configs[2] = SURVEY.md cfg-3: 48 log bands 0.1-10 Hz, alpha 0.5, 6 h @ 40 Hz,
-30 s windows / 50 % overlap, zero-phase Butterworth order 2).
+"""Headline benchmark: (window x band) LTS solves/s.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2|cfg4|cfg5] [--shard bands|traces]
 
-One process per GPU (N > 1: launched by torch.distributed.run, backend nccl = RCCL).  A step is
-one pass of the whole hot path — filter + taper, pairwise cross-correlation / lag pick, MdCCM,
-FAST-LTS + reweighting — over every (band, window) unit of the rank's bands, with the raw trace
-already resident in HBM, plus (N > 1) the single all-gather of the result grids and the D2H copy
-of the grids.  Scaling is weak: every rank runs the same 48 bands over its OWN six-hour trace (an
-independent station-day, generator seed + rank), so per-GPU work is fixed and statistically identical,
-and value = all units of all ranks / max-over-ranks time.  (Sharding the bands of ONE call over the
-GPUs — strong scaling, what narrow_band_least_squares_parallel() does — leaves 6 bands = 4 ms of work per
-GPU at N = 8, which measures launch latency, not the path.)
+A step is ONE WHOLE drop-in call — ``narrow_band_least_squares(...)`` exactly as example.py makes it
+(reference narrow_band_least_squares.py:8-127; SURVEY.md §8(d): "wall time of the whole call including
+H2D/D2H and the final gather"): upload of the raw trace from the stream's own buffers, filter design and
+plan on the host, the device pass (filter + taper, pairwise cross-correlation / lag pick, MdCCM, FAST-LTS +
+reweighting for every (band, window) unit), ONE D2H copy of the result block (grids + packed LTS weights),
+the filter responses, and the reference's dropped-element dictionary ``stdict`` with one entry per window.
+``value`` = units / that wall time.  Beside it: ``kernel_only_ms`` (the device pass alone, HIP events on the
+library's stream), ``value_trace_resident`` (same call without the upload), and ``stage_ms``.  The filter-design
+cache of the host planner is cleared before every step, so no step reuses host work of an earlier one.
 
-The JSON line carries `roofline` (dominant kernel = the cross-correlation; duration measured with
-HIP events on the library's own stream) and `cpu_baseline` (the CPU oracle, band-parallel over
-the host cores like the reference's joblib variant, on a bounded sample of the same workload).
+N = 1: the configuration named by --config (default cfg-3 = BASELINE.json's 8-element metric config; cfg-4 is
+run as ONE GPU's 12-band share of the 96-band / 24 h job, see --band-share).
+N > 1 (one process per GPU, started by ``python -m torch.distributed.run``): --shard bands (default) is ONE
+call of ``narrow_band_least_squares_parallel`` sharded by bands over the ranks with the single RCCL gather
+inside the library (strong scaling: total work fixed); --shard traces gives every rank its own independent
+trace and whole call (weak scaling, no collective).  torch.distributed (gloo) is used by THIS SCRIPT only for
+the barrier around the timed region and the max-over-ranks — the product path has no PyTorch in it.
+
+The JSON line carries ``roofline`` (dominant kernel = the int8-MFMA screening correlator; duration measured
+live with HIP events on the library's stream), ``roofline_hbm`` (the mandated HBM figure: algorithmic bytes /
+wall time), ``noise`` (the same call on an incoherent-noise trace: the screening work is data dependent),
+``cpu_baseline`` (the CPU oracle timed on this box's host cores: 1 core and all cores) and ``env``.
 """
 import argparse
 import json
 import math
 import os
+import platform
 import sys
 import time
 
@@ -31,183 +39,287 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from narrow_band_least_squares_amd import dist, engine, planner, synthetic  # noqa: E402
+from narrow_band_least_squares_amd import (dist, engine, planner, synthetic,  # noqa: E402
+                                           narrow_band_least_squares, narrow_band_least_squares_parallel)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (AMD datasheet; the guide lists none)
 I8_MFMA_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: int8 MFMA = 2x the bf16 dense rate (~2.5 PF) per clock
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+LABELS = {
+    'cfg2': 'cfg-2: 6-element synthetic plane wave, 24 log bands 0.1-5 Hz, LTS alpha=0.75, 1 h @ 20 Hz',
+    'cfg3': 'cfg-3: 8-element synthetic plane wave, 48 log bands 0.1-10 Hz, LTS alpha=0.5, 6 h @ 40 Hz',
+    'cfg4': 'cfg-4: 16-element synthetic plane wave, 96 log bands 0.1-10 Hz, LTS alpha=0.5 (500 LCG starts), 24 h @ 100 Hz',
+    'cfg5': 'cfg-5: 32-element synthetic plane wave, 128 log bands 0.1-5 Hz, LTS alpha=0.5 (500 LCG starts), 1 h @ 20 Hz',
+    'cfg1': 'cfg-1: 6-element synthetic plane wave, 10 linear bands 0.5-5 Hz, OLS, 20 min @ 20 Hz',
+    'cfg1b': 'cfg-1b: example.py parameters, 8-element synthetic, 8 log bands, cheby1, adaptive windows, OLS',
+}
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
 
 
 def cpu_task(args):
     """One band of the CPU oracle (the unit of the reference's joblib parallelism)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import nbls_oracle as o
-    data, fs, rij, fmin, fmax, winlen, alpha = args
+    data, fs, rij, fmin, fmax, winlen, alpha, ftype, order, ripple = args
     st = o.make_stream(data, fs)
-    stf, _, _ = o.filter_data(st, 'butter', fmin, fmax, 2, 0.01)
+    stf, _, _ = o.filter_data(st, ftype, fmin, fmax, order, ripple)
     out = o.ltsva(stf, None, None, winlen, 0.5, alpha, rij=rij)
     return len(out[0])
 
 
-def cpu_baseline(c, edges, budget_s=10.0):
-    """Oracle ("port") timed on the host cores on a bounded sample: one band per core, the first
-    `seconds` of the trace, sized from a probe so that the whole leg takes about `budget_s`."""
+def cpu_baseline(c, edges, winlens, budget_s=8.0):
+    """The oracle ("port": lts_array's source is absent, so the reference's example_parallel.py path cannot
+    run here) timed on the host cores on a bounded sample of the same workload: first on ONE core (one
+    band), then one band per core through joblib — the reference's parallel structure
+    (narrow_band_least_squares.py:285).  The sample is sized from a probe so each leg takes ~budget_s."""
     from joblib import Parallel, delayed
     cores = os.cpu_count() or 1
     nb = min(cores, len(edges))
     pick = [int(round(i * (len(edges) - 1) / max(1, nb - 1))) for i in range(nb)] if nb > 1 else [len(edges) // 2]
     fs = c['fs']
-    probe_s = 150.0
+    data = np.array(c['data'])
+
+    def task(b, npts):
+        return (data[:, :npts], fs, c['rij'], edges[b][0], edges[b][1], winlens[b], c['alpha'], c['ftype'], c['order'],
+                c['ripple'])
+    wl = max(winlens)
+    probe_s = 5.0 * wl
+    mid = pick[len(pick) // 2]
     t = time.time()
-    n = cpu_task((c['data'][:, :int(probe_s * fs)], fs, c['rij'], edges[pick[0]][0], edges[pick[0]][1], 30.0, c['alpha']))
+    n = cpu_task(task(mid, int(probe_s * fs)))
     per_unit = (time.time() - t) / max(1, n)
     units_per_band = max(8, int(budget_s / per_unit))
-    seconds = min(c['dur'], (units_per_band + 1) * 15.0 + 30.0)
+    seconds = min(c['dur'], (units_per_band + 1) * wl * 0.5 + wl)
     npts = int(seconds * fs)
-    tasks = [(c['data'][:, :npts], fs, c['rij'], edges[b][0], edges[b][1], 30.0, c['alpha']) for b in pick]
     t = time.time()
-    counts = Parallel(n_jobs=nb)(delayed(cpu_task)(a) for a in tasks)
+    n1 = cpu_task(task(mid, npts))
+    wall1 = time.time() - t
+    t = time.time()
+    counts = Parallel(n_jobs=nb)(delayed(cpu_task)(task(b, npts)) for b in pick)
     wall = time.time() - t
     return {'value': sum(counts) / wall, 'unit': 'solves/s', 'cores': nb, 'kind': 'port',
-            'sample': '%d bands x first %.0f s of the cfg-3 trace (%d units), NumPy oracle, joblib one band per core'
-                      % (nb, seconds, sum(counts))}
+            'one_core_value': n1 / wall1, 'cpu_model': cpu_model(), 'host_cores': cores,
+            'sample': '%d bands x first %.0f s of the trace (%d units; 1-core leg: 1 band, %d units), NumPy/SciPy oracle, '
+                      'joblib one band per core' % (nb, seconds, sum(counts), n1)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='cfg3')
+    ap.add_argument('--shard', default='bands', choices=['bands', 'traces'],
+                    help='N > 1: one call sharded by bands + RCCL gather (strong scaling) | one trace per rank (weak)')
+    ap.add_argument('--band-share', default=None,
+                    help='"k/n": run only the k-th of n band shares of the config (default 0/8 for cfg4, all bands otherwise)')
     ap.add_argument('--scale', type=float, default=1.0, help='shorten the trace (debug only; invalidates the metric)')
-    ap.add_argument('--xcorr-impl', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-noise', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # under torch.distributed.run the RCCL path is used even for one rank (lets the N>1 code be
-    # rehearsed on a single GPU)
-    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('NBLS_BENCH_FORCE_DIST', '1') == '1')
-    if use_dist:
-        import torch
-        import torch.distributed as td
+    multi = world > 1
+    td = None
+    if multi:
+        import torch.distributed as td          # barrier + max-over-ranks of this script only
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        td.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        td.init_process_group('gloo')
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    shard_traces = multi and args.shard == 'traces'
 
-    c = synthetic.build_config(args.config, scale=args.scale, trace_seed=synthetic.SEED + 1 + rank)
-    bands_per_gpu = c['NBANDS']
-    total_bands = bands_per_gpu
-    freqlist = c['freqlist']
-    all_edges = [(freqlist[i], freqlist[i + 1]) for i in range(total_bands)]
-    edges = all_edges
-    winlens = list(c['WINLEN_list'])
+    seed = synthetic.SEED + 1 + (rank if shard_traces else 0)
+    c = synthetic.build_config(args.config, scale=args.scale, trace_seed=seed)
+    nb_all = c['NBANDS']
+    share = args.band_share or ('0/8' if args.config == 'cfg4' and not multi else None)
+    bands = list(range(nb_all))
+    if share:
+        k, n = (int(x) for x in share.split('/'))
+        npairs = c['N'] * (c['N'] - 1) // 2
+        costs = dist.band_costs(c['npts'], c['fs'], list(c['WINLEN_list']), c['overlap'], npairs)
+        bands = dist.shard_bands(costs, n)[k]
+    freqlist = [c['freqlist'][b] for b in bands] + [c['freqlist'][bands[-1] + 1]]
+    contiguous = bands == list(range(bands[0], bands[-1] + 1))
+    winlens = [c['WINLEN_list'][b] for b in bands]
+    nb = len(bands)
+    st, rij, fs = c['st'], c['rij'], c['fs']
+    nchans, npts = len(st), len(st[0].data)
+    fr = np.logspace(np.log10(0.01), np.log10(fs / 2), 1000)       # example.py:117-119
+    wdummy = np.zeros(len(fr))
 
-    data, fs, t0 = engine.stream_to_array(c['st'])
-    nchans, npts = data.shape
-    h = engine.get_handle(local_rank)
-    h.set_trace(data, fs)                                  # trace resident in HBM before timing
-    xij, pair_idx, xpinv = planner.co_array(c['rij'])
-    h.set_geometry(xij, pair_idx, xpinv)
-    P = xij.shape[0]
-    W, inc, nwin = planner.window_plan(npts, fs, winlens[0], c['overlap'])
-    applied = [planner.design_bandpass(c['ftype'], lo, hi, c['order'], c['ripple'], fs)[0] for lo, hi in edges]
-    sos = planner.pad_sections(applied)
-    tl, tr = planner.taper_ramps(npts)
-    lts = planner.lts_plan(xij, c['alpha']) if c['alpha'] < 1.0 else None
-    vector_len = nwin
-    h.plan(sos, c['ftype'] == 'butter', tl, tr, [W] * len(edges), [inc] * len(edges), vector_len, lts=lts,
-           xcorr_impl=args.xcorr_impl)
+    if contiguous:
+        call_args = (winlens, c['overlap'], c['alpha'], st, None, None, nb, wdummy, wdummy, freqlist, c['band_type'], fr,
+                     c['ftype'], c['order'], c['ripple'])
+    else:
+        # a non-contiguous band share cannot be expressed through freqlist: give every band its own edges
+        # by calling with a 'per-band' list (NBANDS bands, edges b, b+1 of an interleaved list) — instead
+        # use the engine-level entry with explicit edges
+        call_args = None
+    edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in bands]
+
+    h = engine.get_handle(local_rank if multi else None)
     h.set_profiling(True)
-    units_rank = nwin * len(edges)
 
-    def sync_all():
+    def one_call(stream, resident=False):
+        planner.design_cache_clear()
+        if multi and not shard_traces:
+            return narrow_band_least_squares_parallel(*call_args[:3], stream, *call_args[4:], rij=rij)
+        if call_args is not None and not resident:
+            return narrow_band_least_squares(*call_args[:3], stream, *call_args[4:], rij=rij)
+        return share_call(stream, resident)
+
+    def share_call(stream, resident):
+        """The same whole call for a non-contiguous band share (or with the trace left resident): the body of
+        narrow_band_least_squares() with explicit band edges."""
+        from narrow_band_least_squares_amd.narrow_band_least_squares import _band_prefix, _vector_len
+        from scipy import signal
+        rows, fs_, t0 = engine.stream_rows(stream)
+        vl = _vector_len(winlens, c['overlap'], stream)
+        w_rows = np.zeros((nb, len(fr)), dtype=complex)
+        h_rows = np.zeros((nb, len(fr)), dtype=complex)
+
+        def host_side(res):
+            for n_, s_ in enumerate(res.sos):
+                w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_)
+            if c['alpha'] < 1.0:
+                res.keys = engine.time_keys(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
+        res = engine.process(rows, fs_, t0, rij, edges, winlens, c['overlap'], c['alpha'], c['ftype'], c['order'],
+                             c['ripple'], vector_len=vl, host_overlap=host_side, upload=not resident, handle=h)
+        sd = None if c['alpha'] == 1.0 else engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
+        return (res.vel, res.baz, res.mdccm, res.t, sd, res.sigma_tau, [int(x) for x in res.nwin], w_rows, h_rows)
+
+    def barrier():
         h.sync()
-        if use_dist:
+        if multi:
             td.barrier()
-            torch.cuda.synchronize()
 
-    def step():
-        h.execute()
-        h.sync()
-        if use_dist:
-            ptrs, nbytes = h.device_results()
-            dist.all_gather_device_grids(ptrs, nbytes, (len(edges), vector_len), local_rank)
-        else:
-            h.fetch()
+    def timed(stream, steps, resident=False):
+        kern, stages = [], []
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = one_call(stream, resident)
+            tm = h.timings()
+            kern.append(tm['total_ms'])
+            stages.append(tm)
+        barrier()
+        el = time.perf_counter() - t0
+        if multi:
+            import torch
+            tt = torch.tensor([el], dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, kern, stages, out
 
     for _ in range(args.warmup):
-        step()
-    sync_all()
-    xc, fl, sv, scr, qz, vf = [], [], [], [], [], []
-    impl_used = 0
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tm = h.timings()
-        xc.append(tm['xcorr_ms']); fl.append(tm['filter_ms']); sv.append(tm['solve_ms'])
-        scr.append(tm['screen_ms']); qz.append(tm['quantize_ms']); vf.append(tm['verify_ms'])
-        impl_used = tm['xcorr_impl']
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    total_units = units_rank * world
+        one_call(st)
+    elapsed, kern, stages, out = timed(st, args.steps)
+    nwin_list = out[6]
+    units_call = int(sum(nwin_list))
+    total_units = units_call * (world if shard_traces else 1)
     value = total_units * args.steps / elapsed
+    ms_step = elapsed / args.steps * 1e3
 
+    line = None
     if rank == 0:
-        xcorr_ms = float(np.mean(xc))
-        flop_unit = 2.0 * P * float(W) * float(W)
-        bytes_unit = 8.0 * nchans * inc + 40.0 + math.ceil(P / 8)
-        # dominant kernel: the int8-MFMA screening kernel (impl 3), else the f64-MFMA / VALU correlator
+        P = nchans * (nchans - 1) // 2
+        Wb = np.array([int(wl * fs) for wl in winlens], dtype=np.float64)
+        incb = np.array([int(np.round((1 - c['overlap']) * w)) for w in Wb], dtype=np.float64)
+        nw = np.array(nwin_list, dtype=np.float64)
+        units_gpu = units_call if (not multi or shard_traces) else units_call / world
+        flop_total = float(np.sum(2.0 * P * Wb * Wb * nw))                    # algorithmic 2 P W^2 per unit
+        bytes_total = float(np.sum((8.0 * nchans * incb + 40.0 + math.ceil(P / 8)) * nw))
+        mean = lambda k: float(np.mean([s[k] for s in stages]))   # noqa: E731
+        impl_used = stages[-1]['xcorr_impl']
+        kernel_only = float(np.mean(kern))
         if impl_used == 3:
-            kern, kern_ms, peak = 'screen_kernel (int8 MFMA screening of the full-lag correlation)', float(np.mean(scr)), I8_MFMA_PEAK_TOPS
+            kname, kern_ms, peak = 'screen_kernel (int8 MFMA screening of the full-lag correlation)', mean('screen_ms'), I8_MFMA_PEAK_TOPS
         else:
-            kern, kern_ms, peak = 'xcorr_mfma_kernel (f64 MFMA)' if impl_used == 2 else 'xcorr_simple_kernel', xcorr_ms, FP64_MFMA_PEAK_TFLOPS
-        achieved_tf = flop_unit * units_rank / (kern_ms * 1e-3) / 1e12
-        achieved_gbs = bytes_unit * units_rank / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tf):
+            kname = 'xcorr_mfma_kernel (f64 MFMA)' if impl_used == 2 else 'xcorr_simple_kernel'
+            kern_ms, peak = mean('xcorr_ms'), FP64_MFMA_PEAK_TFLOPS
+        share_f = (1.0 / world) if (multi and not shard_traces) else 1.0      # this rank's part of the call
+        achieved_tf = flop_total * share_f / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tf)).get(args.config, {}).get('xcorr_hbm_bytes_per_launch')
+                tj = json.load(open(tfile)).get(args.config)
+                if tj:
+                    traffic = float(tj['xcorr_hbm_bytes_per_launch'])
+                    traffic_src = 'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (%s)' % tj.get('tag', 'r02')
             except Exception:
                 traffic = None
+        launches = int(stages[-1]['xcorr_launches'])
         line = {
             'metric': '(window x band) LTS solves/sec, 8-element synthetic', 'value': value, 'unit': 'solves/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'higher_is_better': True, 'scaling': 'weak' if (shard_traces or not multi) else 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cfg-3: 8-element synthetic plane wave, %d log bands 0.1-10 Hz, LTS alpha=0.5, '
-                                   '6 h @ 40 Hz, 30 s windows 50%% overlap, butter order 2 zero-phase; one '
-                                   'independent 6 h trace per GPU (%d trace(s))' % (bands_per_gpu, world),
-                       'units_per_gpu': units_rank, 'elements': nchans, 'pairs': P, 'window_samples': W,
-                       'lts_starts': None if lts is None else int(lts['starts'].shape[0]),
-                       'parallelism': '%d GPU(s), (band x window x trace) units sharded by trace, one all-gather '
-                                      'of the grids' % world,
+            'config': {'workload': LABELS.get(args.config, args.config) + ', %s s windows %d%% overlap, %s order %d%s'
+                                   % ('/'.join(sorted({str(w) for w in winlens}, key=float)), int(round(c['overlap'] * 100)), c['ftype'], c['order'],
+                                      ' zero-phase' if c['ftype'] == 'butter' else '')
+                                   + ('; band share %s (%d of %d bands)' % (share, nb, nb_all) if share else ''),
+                       'step': 'one whole narrow_band_least_squares%s() call: trace upload, filter design + plan, device pass, '
+                               'one D2H of grids + packed LTS weights, filter responses, stdict (%d entries)'
+                               % ('_parallel' if multi and not shard_traces else '', 0 if out[4] is None else len(out[4])),
+                       'units_per_call': units_call, 'bands': nb, 'elements': nchans, 'pairs': P,
+                       'window_samples': sorted({int(w) for w in Wb}),
+                       'parallelism': ('1 GPU' if not multi else
+                                       ('%d GPUs, bands of one call sharded by cost, one RCCL gather in the library' % world
+                                        if not shard_traces else '%d GPUs, one independent trace and whole call per rank, no collective' % world)),
                        'scale': args.scale},
-            'stage_ms': {'filter': float(np.mean(fl)), 'xcorr': xcorr_ms, 'solve': float(np.mean(sv)),
-                         'xcorr_quantize': float(np.mean(qz)), 'xcorr_screen': float(np.mean(scr)),
-                         'xcorr_verify': float(np.mean(vf))},
+            'kernel_only_ms': kernel_only,
+            'kernel_only_value': units_gpu / (kernel_only * 1e-3) * (world if multi else 1),
+            'stage_ms': {'filter': mean('filter_ms'), 'xcorr': mean('xcorr_ms'), 'solve': mean('solve_ms'),
+                         'xcorr_quantize': mean('quantize_ms'), 'xcorr_screen': mean('screen_ms'),
+                         'xcorr_verify': mean('verify_ms')},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / peak, 'traffic': traffic, 'kernel': kern,
-                         'flop_per_unit': flop_unit, 'kernel_ms_per_step': kern_ms,
-                         'launches_per_step': int(h.timings()['xcorr_launches']),
-                         'note': 'achieved = algorithmic 2*P*W^2 flop per unit x units / kernel time; the screening '
-                                 'kernel issues 3 int8 limb products per algorithmic multiply-add (the low x low product is bounded, not computed)'},
-            'roofline_hbm': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'bytes_per_unit': bytes_unit},
+                         'frac': achieved_tf / peak, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
+                         'kernel_ms_per_step': kern_ms, 'launches_per_step': launches,
+                         'note': 'ALGORITHMIC fraction: 2*P*W^2 flop per unit x units / kernel time, not issued work '
+                                 '(the screening kernel issues 3 int8 limb products per multiply-add and skips lag '
+                                 'blocks that cannot hold the maximum; see `noise` for the input without coherent signal)'},
+            'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_total / (ms_step * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': bytes_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'frac_kernel_only': bytes_total * share_f / (kernel_only * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'bytes_per_call': bytes_total,
+                             'note': 'SURVEY 8(d): algorithmic bytes (8*N*inc + 40 + ceil(P/8) per unit) / wall time of the whole call'},
+            'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('NBLS_')},
         }
+    # the same call with the trace already resident in HBM (no upload) ...
+    el_r, kern_r, _, _ = timed(st, max(2, args.steps // 2), resident=True) if not (multi and not shard_traces) else (None, None, None, None)
+    if rank == 0 and el_r is not None:
+        line['value_trace_resident'] = total_units * max(2, args.steps // 2) / el_r
+    # ... and on incoherent noise of the same shape (no common signal: nothing for the pruning to exploit)
+    if not args.no_noise and not multi:
+        rng = np.random.default_rng(7)
+        noise = synthetic.make_stream(rng.standard_normal((nchans, npts)), fs)
+        one_call(noise)
+        el_n, kern_n, stages_n, _ = timed(noise, max(2, args.steps // 2))
+        line['noise'] = {'value': units_call * max(2, args.steps // 2) / el_n, 'ms_per_step': el_n / max(2, args.steps // 2) * 1e3,
+                         'kernel_only_ms': float(np.mean(kern_n)),
+                         'xcorr_screen_ms': float(np.mean([s['screen_ms'] for s in stages_n])),
+                         'xcorr_verify_ms': float(np.mean([s['verify_ms'] for s in stages_n])),
+                         'input': 'independent white Gaussian noise on every element, same shape and bands'}
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(c, all_edges)
+            line['cpu_baseline'] = cpu_baseline(c, edges, winlens)
         print(json.dumps(line), flush=True)
-    if use_dist:
+    if multi:
         td.barrier()
         td.destroy_process_group()
 

@@ -17,7 +17,7 @@
  *   nbls_execute        <- one pass of the band loop body for every planned band:
  *                          helpers.py:124-139 (filter + taper) and ltsva
  *                          (narrow_band_least_squares.py:91 / :183)
- *   nbls_fetch          <- the result rows written at narrow_band_least_squares.py:104-113
+ *   nbls_fetch[_packed] <- the result rows written at narrow_band_least_squares.py:104-113
  *                          (vel/baz/mdccm/sigma_tau), the lag vectors tau and the LTS
  *                          weights that become `stdict` (:114-124)
  *   nbls_run            <- convenience: plan + execute + sync + fetch
@@ -45,7 +45,8 @@ typedef enum {
     NBLS_ERR_GEOMETRY = -3,   /* < 3 elements, < 4 for LTS, rank-deficient co-array   */
     NBLS_ERR_HIP = -4,        /* HIP runtime failure                                  */
     NBLS_ERR_NOMEM = -5,      /* device allocation failed                             */
-    NBLS_ERR_UNSUPPORTED = -6 /* size beyond what the kernels are built for           */
+    NBLS_ERR_UNSUPPORTED = -6,/* size beyond what the kernels are built for           */
+    NBLS_ERR_COMM = -7        /* RCCL not loadable / communicator failure             */
 } nbls_status;
 
 /* FAST-LTS parameters (lts_array LTSEstimator / robustbase ltsReg; host computes them). */
@@ -79,6 +80,8 @@ typedef struct {
 } nbls_timings;
 
 int nbls_version(void);
+/* Number of visible HIP devices (0 if the runtime cannot be initialised). */
+int nbls_device_count(void);
 
 /* Create a handle on HIP device `device_id` (lazy HIP init happens here, so it is safe to
  * fork before the first call).  *out is NULL on failure; nbls_last_error(NULL) explains. */
@@ -89,6 +92,10 @@ const char* nbls_last_error(const nbls_handle* h);
 /* Raw multichannel trace, channel-major contiguous trace[nchans][npts], copied to HBM and
  * kept resident until the next nbls_set_trace. */
 int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs);
+
+/* Same, from one pointer per channel (rows[c][npts], each contiguous): the traces of an obspy-like
+ * Stream are separate arrays, this form uploads them without first packing them into one host block. */
+int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts, double fs);
 
 /* Co-array: xij[npairs][2] (km; pair k = (i,j), i<j, lexicographic; xij = r_i - r_j),
  * pair_idx[npairs][2], xpinv[2][npairs] = pseudo-inverse of xij (OLS). */
@@ -142,9 +149,50 @@ int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out);
 
 /* Device pointers of the result grids (for an RCCL gather straight from HBM):
  * ptrs[0..3] = vel, baz, mdccm, sigma_tau (double[nbands][vector_len]); ptrs[4] = nwin (int32).
- * The four grids are allocated as one block: right after a plan that (re)allocated them they are
- * contiguous (ptrs[i+1] - ptrs[i] == *bytes_per_grid), so one collective can move all four. */
+ * The four grids are the head of the result block (see nbls_result_layout): always contiguous,
+ * ptrs[i+1] - ptrs[i] == *bytes_per_grid. */
 int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid);
+
+/* The result block: ONE device allocation holding, back to back,
+ *     double vel[B][VL], baz[B][VL], mdccm[B][VL], sigma_tau[B][VL], uint8 mask[B][VL][MB]
+ * MB = ceil(npairs / 8); bit (k & 7) of mask byte (k >> 3) is the LTS weight of pair k (1 = kept; all
+ * 1 for OLS; rows beyond nwin[b] are zero).  This is what narrow_band_least_squares() needs back from
+ * the GPU (rows written at narrow_band_least_squares.py:104-113 + the weights behind `stdict`, :114-124).
+ *   nbls_result_layout: out4 = {cells = B*VL, MB, total bytes, byte offset of the mask}
+ *   nbls_fetch_packed : one D2H copy of the whole block into out[nbytes] (nbytes = total bytes) */
+int nbls_result_layout(nbls_handle* h, int64_t* out4);
+int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes);
+
+/* ---- multi-GPU: ONE grouped RCCL operation collects every GPU's result block ----------------------
+ * Replaces the joblib fan-out / collection of narrow_band_least_squares_parallel()
+ * (narrow_band_least_squares.py:285 and :291-320).  Bands (or window slices) are sharded by the host;
+ * every GPU runs nbls_plan/nbls_execute for its share; nbls_comm_gather moves the blocks over xGMI.
+ *
+ *   nbls_comm_init_all(hs, n)       one process, n handles on n different devices (ncclCommInitAll);
+ *                                   handle i becomes rank i of n
+ *   nbls_comm_unique_id(id, 128)    rank 0 of a multi-process job creates the communicator id ...
+ *   nbls_comm_init_rank(h, id, world, rank)   ... and every process (one GPU each) joins with it; the
+ *                                   128 id bytes travel by any side channel (the Python host: a TCP socket)
+ *   nbls_reserve_results(h, bytes)  make the NEXT plans allocate the result block with at least
+ *                                   `bytes` (= the common block size of the gather: ranks hold
+ *                                   different numbers of bands, the gather needs equal blocks)
+ *   nbls_comm_gather(hs, n, root, block_bytes, status, host_out, host_bytes)
+ *       hs[0..n): the handles this process drives (n = 1 with one process per GPU).  Every rank sends
+ *       block_bytes (a multiple of 8, >= its result block + 8): its result block, padding, and in the
+ *       last 8 bytes `status` (int64; 0 = this rank's pass succeeded — lets a failed rank still take
+ *       part so that nobody hangs; pass the rank's error code otherwise).  root >= 0: gather to that
+ *       rank (grouped ncclSend/ncclRecv); root < 0: ncclAllGather.  The process that drives the root
+ *       (all-gather: every process) receives host_out[world][block_bytes]; other processes may pass NULL.
+ *       The operation is ordered on the handles' streams after their nbls_execute and returns after the
+ *       copy to the host has finished.
+ *   nbls_comm_destroy(h)            release the communicator (also done by nbls_destroy)           */
+int nbls_comm_init_all(nbls_handle* const* hs, int32_t n);
+int nbls_comm_unique_id(void* id, int32_t nbytes);
+int nbls_comm_init_rank(nbls_handle* h, const void* id, int32_t world, int32_t rank);
+int nbls_reserve_results(nbls_handle* h, int64_t bytes);
+int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t block_bytes, int64_t status,
+                     void* host_out, int64_t host_bytes);
+int nbls_comm_destroy(nbls_handle* h);
 
 /* Enable (1) / disable (0) HIP-event timing of the stages; read the last run's timings. */
 int nbls_set_profiling(nbls_handle* h, int32_t on);

@@ -12,14 +12,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libnbls_hip.so')
 
 EXPORTS = [
-    'nbls_version', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
+    'nbls_version', 'nbls_device_count', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
     'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
+    'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
+    'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
-NBLS_ERR_HIP, NBLS_ERR_NOMEM, NBLS_ERR_UNSUPPORTED = -4, -5, -6
+NBLS_ERR_HIP, NBLS_ERR_NOMEM, NBLS_ERR_UNSUPPORTED, NBLS_ERR_COMM = -4, -5, -6, -7
 
 
 class NblsError(RuntimeError):
@@ -68,6 +70,15 @@ def load_library(path=None):
     lib.nbls_last_error.argtypes = [vp]
     lib.nbls_last_error.restype = C.c_char_p
     lib.nbls_set_trace.argtypes = [vp, dp, C.c_int32, C.c_int64, C.c_double]
+    lib.nbls_set_trace_rows.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_double]
+    lib.nbls_result_layout.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.nbls_fetch_packed.argtypes = [vp, C.c_void_p, C.c_int64]
+    lib.nbls_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32]
+    lib.nbls_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
+    lib.nbls_comm_init_rank.argtypes = [vp, C.c_void_p, C.c_int32, C.c_int32]
+    lib.nbls_reserve_results.argtypes = [vp, C.c_int64]
+    lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+    lib.nbls_comm_destroy.argtypes = [vp]
     lib.nbls_set_geometry.argtypes = [vp, dp, ip, dp, C.c_int32]
     plan_args = [vp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip, ip, C.c_int32,
                  C.POINTER(LtsParams), C.c_int32]
@@ -154,6 +165,22 @@ class Handle:
         self._chk(self.lib.nbls_set_trace(self._h, _dptr(data), data.shape[0], data.shape[1], float(fs)))
         self.nchans, self.npts, self.fs = data.shape[0], data.shape[1], float(fs)
 
+    def set_trace_rows(self, rows, fs):
+        """rows: one 1-D float64 C-contiguous array per channel, all of the same length (uploaded
+        straight from where they are: no packed host copy)."""
+        npts = len(rows[0])
+        keep = []
+        for r in rows:
+            r = np.asarray(r)
+            if r.dtype != np.float64 or not r.flags.c_contiguous:
+                r = np.ascontiguousarray(r, dtype=np.float64)
+            if r.ndim != 1 or len(r) != npts:
+                raise ValueError('All traces must have the same number of samples.')
+            keep.append(r)
+        ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
+        self._chk(self.lib.nbls_set_trace_rows(self._h, ptrs, len(keep), npts, float(fs)))
+        self.nchans, self.npts, self.fs = len(keep), npts, float(fs)
+
     def set_geometry(self, xij, pair_idx, xpinv):
         xij = _f64(xij)
         pair_idx = np.ascontiguousarray(pair_idx, dtype=np.int32)
@@ -204,6 +231,10 @@ class Handle:
                                      int(xcorr_impl)))
         self.nbands, self.vector_len = nb, int(vector_len)
 
+    def reserve_results(self, nbytes):
+        """Minimum allocation of the result block for the next plans (equal-sized gather blocks)."""
+        self._chk(self.lib.nbls_reserve_results(self._h, int(nbytes)))
+
     def set_window_ranges(self, first=None, count=None):
         """Per-band window slices for the next plan(s); None resets to "all windows"."""
         if first is None:
@@ -219,10 +250,13 @@ class Handle:
     def sync(self):
         self._chk(self.lib.nbls_sync(self._h))
 
-    def fetch(self, want_lag=False, want_cmax=False, want_weights=False, want_z=False):
+    def fetch(self, want_lag=False, want_cmax=False, want_weights=False, want_z=False, grids=True):
         B, VL, P = self.nbands, self.vector_len, self.npairs
-        out = dict(vel=np.empty((B, VL)), baz=np.empty((B, VL)), mdccm=np.empty((B, VL)),
-                   sigma_tau=np.empty((B, VL)), nwin=np.empty(B, dtype=np.int32))
+        if grids:
+            g = np.empty((4, B, VL))               # one block: nbls_fetch moves the four grids in one copy
+            out = dict(vel=g[0], baz=g[1], mdccm=g[2], sigma_tau=g[3], nwin=np.empty(B, dtype=np.int32))
+        else:
+            out = dict(vel=None, baz=None, mdccm=None, sigma_tau=None, nwin=np.empty(B, dtype=np.int32))
         lag = np.empty((B, VL, P), dtype=np.int32) if want_lag else None
         cmax = np.empty((B, VL, P)) if want_cmax else None
         wts = np.empty((B, VL, P), dtype=np.uint8) if want_weights else None
@@ -232,6 +266,19 @@ class Handle:
                                       _u8ptr(wts), _dptr(z)))
         out.update(lag=lag, cmax=cmax, weights=wts, z=z)
         return out
+
+    def fetch_packed(self):
+        """One D2H copy of the result block -> dict(vel, baz, mdccm, sigma_tau (B, VL) float64 views of one
+        buffer, mask (B, VL, ceil(P/8)) uint8: bit k & 7 of byte k >> 3 = LTS weight of pair k)."""
+        lay = (C.c_int64 * 4)()
+        self._chk(self.lib.nbls_result_layout(self._h, lay))
+        cells, mb, total, moff = lay[0], lay[1], lay[2], lay[3]
+        buf = np.empty(total // 8 + 1, dtype=np.float64)       # 8-byte aligned
+        self._chk(self.lib.nbls_fetch_packed(self._h, buf.ctypes.data, total))
+        B, VL = self.nbands, self.vector_len
+        grids = buf[:4 * cells].reshape(4, B, VL)
+        mask = buf.view(np.uint8)[moff:moff + cells * mb].reshape(B, VL, mb)
+        return dict(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], mask=mask)
 
     def fetch_filtered(self, band):
         out = np.empty((self.nchans, self.npts))

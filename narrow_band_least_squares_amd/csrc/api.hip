@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 
 namespace {
@@ -40,10 +41,18 @@ int ensure(nbls_handle* h, T** p, size_t* cap, size_t need_bytes) {
     return 0;
 }
 
+// Upload a small plan table.  The allocation is kept and reused while it is big enough (hipFree
+// synchronises the device and hipMalloc is slow: a plan uploads ~15 of these); its capacity is
+// remembered in h->caps under the address of the pointer member.
 template <typename T>
 int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
-    HIPCHK(h, hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    const size_t need = (n ? n : 1) * sizeof(T);
+    size_t& cap = h->caps[(const void*)p];
+    if (!*p || cap < need) {
+        if (*p) { (void)hipFree(*p); *p = nullptr; cap = 0; }
+        HIPCHK(h, hipMalloc((void**)p, need));
+        cap = need;
+    }
     if (n) HIPCHK(h, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
@@ -53,9 +62,11 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
 //   fw[t][d]    = (A^(C-1-t) g)[d]         zero-state end state  e = sum_t fw[t] x_t
 //   mpow[j]     = (A^C)^j, j = 0..G        chunk / group transitions
 void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
+    constexpr int DM = 2 * NBLS_MAX_SECTIONS;
     const int D = 2 * S;
     typedef long double ld;
-    auto step = [&](std::vector<ld>& st, ld x) {
+    // fixed-size stack matrices (D <= 16): this runs for every band of every plan
+    auto step = [&](ld* st, ld x) {
         ld v = x;
         for (int s = 0; s < S; ++s) {
             const ld b0 = sos[s * 6 + 0], b1 = sos[s * 6 + 1], b2 = sos[s * 6 + 2];
@@ -68,43 +79,53 @@ void filter_tables(const double* sos, int S, int C, int G, double* fw, double* m
             v = y;
         }
     };
-    std::vector<ld> A(D * D), g(D, 0.0L);
+    ld A[DM * DM], g[DM];
     for (int col = 0; col < D; ++col) {
-        std::vector<ld> st(D, 0.0L);
+        ld st[DM];
+        for (int r = 0; r < D; ++r) st[r] = 0.0L;
         st[col] = 1.0L;
         step(st, 0.0L);
         for (int r = 0; r < D; ++r) A[r * D + col] = st[r];
     }
+    for (int r = 0; r < D; ++r) g[r] = 0.0L;
     step(g, 1.0L);
-    auto matvec = [&](const std::vector<ld>& Mx, const std::vector<ld>& v) {
-        std::vector<ld> o(D, 0.0L);
+    auto matmul = [&](const ld* X, const ld* Y, ld* o) {          // o = X Y (o distinct from X, Y)
         for (int i = 0; i < D; ++i)
-            for (int k = 0; k < D; ++k) o[i] += Mx[i * D + k] * v[k];
-        return o;
+            for (int j = 0; j < D; ++j) {
+                ld acc = 0.0L;
+                for (int k = 0; k < D; ++k) acc += X[i * D + k] * Y[k * D + j];
+                o[i * D + j] = acc;
+            }
     };
-    auto matmul = [&](const std::vector<ld>& X, const std::vector<ld>& Y) {
-        std::vector<ld> o(D * D, 0.0L);
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j)
-                for (int k = 0; k < D; ++k) o[i * D + j] += X[i * D + k] * Y[k * D + j];
-        return o;
-    };
-    std::vector<ld> v = g;
-    for (int k = 0; k < C; ++k) {            // v = A^k g  ->  weight of sample t = C-1-k
+    // v = A^k g is the weight of sample t = C-1-k.  One DF2T step with input 0 IS the product A v
+    // (A's columns were made by that same step), at O(S) instead of O(D^2) operations.
+    ld v[DM];
+    for (int d = 0; d < D; ++d) v[d] = g[d];
+    for (int k = 0; k < C; ++k) {
         for (int d = 0; d < D; ++d) fw[(size_t)(C - 1 - k) * D + d] = (double)v[d];
-        v = matvec(A, v);
+        ld nv[DM];
+        for (int i = 0; i < D; ++i) {
+            ld acc = 0.0L;
+            for (int q = 0; q < D; ++q) acc += A[i * D + q] * v[q];
+            nv[i] = acc;
+        }
+        for (int d = 0; d < D; ++d) v[d] = nv[d];
     }
-    std::vector<ld> M(D * D, 0.0L), B = A;   // M = A^C by squaring
+    ld M[DM * DM], Bm[DM * DM], T[DM * DM];                       // M = A^C by squaring
+    for (int i = 0; i < D * D; ++i) { M[i] = 0.0L; Bm[i] = A[i]; }
     for (int i = 0; i < D; ++i) M[i * D + i] = 1.0L;
     for (int e = C; e > 0; e >>= 1) {
-        if (e & 1) M = matmul(M, B);
-        B = matmul(B, B);
+        if (e & 1) { matmul(M, Bm, T); for (int i = 0; i < D * D; ++i) M[i] = T[i]; }
+        matmul(Bm, Bm, T);
+        for (int i = 0; i < D * D; ++i) Bm[i] = T[i];
     }
-    std::vector<ld> Pw(D * D, 0.0L);
+    ld Pw[DM * DM];
+    for (int i = 0; i < D * D; ++i) Pw[i] = 0.0L;
     for (int i = 0; i < D; ++i) Pw[i * D + i] = 1.0L;
     for (int j = 0; j <= G; ++j) {
         for (int i = 0; i < D * D; ++i) mpow[(size_t)j * D * D + i] = (double)Pw[i];
-        Pw = matmul(Pw, M);
+        matmul(Pw, M, T);
+        for (int i = 0; i < D * D; ++i) Pw[i] = T[i];
     }
 }
 
@@ -112,12 +133,18 @@ void filter_tables(const double* sos, int S, int C, int G, double* fw, double* m
 
 extern "C" {
 
-int nbls_version(void) { return 100; }
+int nbls_version(void) { return 200; }
 
 const char* nbls_last_error(const nbls_handle* h) {
     if (h) return h->err.c_str();
     std::lock_guard<std::mutex> l(g_err_mu);
     return g_err.c_str();
+}
+
+int nbls_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
 }
 
 int nbls_create(int device_id, nbls_handle** out) {
@@ -147,9 +174,10 @@ void nbls_destroy(nbls_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)nbls_comm_destroy(h);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2,
-                    h->d_lag, h->d_cmax, h->d_vel /* + baz, mdccm, sigma_tau */, h->d_z, h->d_wts,
+                    h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -160,19 +188,31 @@ void nbls_destroy(nbls_handle* h) {
     delete h;
 }
 
-int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs) {
-    if (!h) return NBLS_ERR_ARG;
-    if (!trace || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace: bad argument");
+static int set_trace_impl(nbls_handle* h, const double* const* rows, const double* flat, int32_t nchans, int64_t npts,
+                          double fs) {
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t pad = (npts + 63) / 64 * 64;
-    if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; }
-    HIPCHK(h, hipMalloc((void**)&h->d_trace, (size_t)nchans * pad * sizeof(double)));
-    HIPCHK(h, hipMemsetAsync(h->d_trace, 0, (size_t)nchans * pad * sizeof(double), h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->d_trace, pad * sizeof(double), trace, npts * sizeof(double),
-                               npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->stream));
+    const size_t need = (size_t)nchans * pad * sizeof(double);
+    if (!h->d_trace || h->cap_trace < need) {
+        if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; h->cap_trace = 0; }
+        HIPCHK(h, hipMalloc((void**)&h->d_trace, need));
+        h->cap_trace = need;
+    }
+    if (pad > npts)
+        HIPCHK(h, hipMemset2DAsync(h->d_trace + npts, pad * sizeof(double), 0, (pad - npts) * sizeof(double), nchans, h->stream));
+    if (flat) {
+        HIPCHK(h, hipMemcpy2DAsync(h->d_trace, pad * sizeof(double), flat, npts * sizeof(double),
+                                   npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int c = 0; c < nchans; ++c)
+            HIPCHK(h, hipMemcpyAsync(h->d_trace + (size_t)c * pad, rows[c], npts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    // the caller's buffers may be reused as soon as this returns (pageable sources are staged before
+    // hipMemcpyAsync returns; pinned ones are still being read): wait for the copies
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->nchans != nchans && h->d_xij) {      // a geometry of another array size is stale
         (void)hipFree(h->d_xij); h->d_xij = nullptr;
+        h->caps.erase((const void*)&h->d_xij);
         h->npairs = 0;
     }
     h->nchans = nchans;
@@ -181,6 +221,20 @@ int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t 
     h->fs = fs;
     h->planned = false;
     return NBLS_OK;
+}
+
+int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!trace || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace: bad argument");
+    return set_trace_impl(h, nullptr, trace, nchans, npts, fs);
+}
+
+int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts, double fs) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!rows || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace_rows: bad argument");
+    for (int c = 0; c < nchans; ++c)
+        if (!rows[c]) return fail(h, NBLS_ERR_ARG, "nbls_set_trace_rows: NULL row pointer");
+    return set_trace_impl(h, rows, nullptr, nchans, npts, fs);
 }
 
 int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx, const double* xpinv,
@@ -293,12 +347,14 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     h->nchunks = (h->npts + NBLS_FILTER_CHUNK - 1) / NBLS_FILTER_CHUNK;
 
     int rc;
+    const auto tp0 = std::chrono::steady_clock::now();
     const int D = 2 * nsections;
     const int GG = NBLS_FILTER_GROUP;
     std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
     for (int b = 0; b < nbands && nsections > 0; ++b)
         filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
                       &FW[(size_t)b * NBLS_FILTER_CHUNK * D], &M[(size_t)b * (GG + 1) * D * D]);
+    const auto tp1 = std::chrono::steady_clock::now();
     if ((rc = alloc_copy(h, &h->d_fw, FW.data(), FW.size()))) return rc;
     if ((rc = alloc_copy(h, &h->d_sos, sos, (size_t)nbands * nsections * 6))) return rc;
     if (nsections == 0 && nbands != 1)
@@ -322,6 +378,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if ((rc = alloc_copy(h, &h->d_unit_win, uw.data(), (size_t)U))) return rc;
     }
 
+    const auto tp2 = std::chrono::steady_clock::now();
     const size_t nseries = (size_t)nbands * h->nchans;
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
@@ -329,32 +386,23 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const size_t ngroups = (size_t)((h->nchunks + NBLS_FILTER_GROUP - 1) / NBLS_FILTER_GROUP);
     if ((rc = ensure(h, &h->d_gend, &h->cap_gend, nseries * ngroups * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_gin, &h->cap_gin, nseries * ngroups * D * sizeof(double)))) return rc;
-    // results: one arena sized for [B][VL] grids
+    // results: every buffer has its own capacity; the views into the result block are recomputed by
+    // every plan (a smaller plan after a bigger one keeps the allocation but must move the grid offsets)
     const size_t cells = (size_t)nbands * vector_len;
-    const size_t need = cells * sizeof(double);
-    if (need > h->cap_res) {
-        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_z, h->d_wts};      // (baz, mdccm, sig live in d_vel's block)
-        for (void* p : olds) if (p) (void)hipFree(p);
-        h->d_lag = nullptr; h->d_cmax = nullptr; h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = h->d_z = nullptr; h->d_wts = nullptr;
-        h->cap_res = 0;
-    }
-    if (!h->d_vel || h->cap_units < cells * P) {
-        void* olds[] = {h->d_lag, h->d_cmax, h->d_vel, h->d_z, h->d_wts};
-        for (void* p : olds) if (p) (void)hipFree(p);
-        h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = nullptr;
-        HIPCHK(h, hipMalloc((void**)&h->d_lag, cells * P * sizeof(int32_t)));
-        HIPCHK(h, hipMalloc((void**)&h->d_cmax, cells * P * sizeof(double)));
-        // the four result grids are one block (vel | baz | mdccm | sigma_tau): a multi-GPU caller can
-        // all-gather them with one collective straight from HBM
-        HIPCHK(h, hipMalloc((void**)&h->d_vel, 4 * need));
-        h->d_baz = h->d_vel + cells;
-        h->d_mdccm = h->d_baz + cells;
-        h->d_sig = h->d_mdccm + cells;
-        HIPCHK(h, hipMalloc((void**)&h->d_z, 2 * need));
-        HIPCHK(h, hipMalloc((void**)&h->d_wts, cells * P));
-        h->cap_res = need;
-        h->cap_units = cells * P;
-    }
+    h->mask_bytes = (P + 7) / 8;
+    h->res_bytes = cells * (4 * sizeof(double) + (size_t)h->mask_bytes);
+    h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = nullptr;
+    h->d_mask = nullptr;
+    if ((rc = ensure(h, &h->d_res, &h->cap_res, h->res_bytes > h->reserve_res ? h->res_bytes : h->reserve_res))) return rc;
+    if ((rc = ensure(h, &h->d_lag, &h->cap_lag, cells * P * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(h, &h->d_cmax, &h->cap_cmax, cells * P * sizeof(double)))) return rc;
+    if ((rc = ensure(h, &h->d_z, &h->cap_z, 2 * cells * sizeof(double)))) return rc;
+    if ((rc = ensure(h, &h->d_wts, &h->cap_wts, cells * P))) return rc;
+    h->d_vel = (double*)h->d_res;
+    h->d_baz = h->d_vel + cells;
+    h->d_mdccm = h->d_baz + cells;
+    h->d_sig = h->d_mdccm + cells;
+    h->d_mask = h->d_res + 4 * cells * sizeof(double);
 
     {   // resolve "auto": int8 screening when the array/window fit it, else f64 MFMA, else plain VALU
         int S_, PFB_, CSB_, CSA_, WP_, nsl_;
@@ -399,6 +447,11 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if ((rc = alloc_copy(h, &h->d_xs, xs.data(), xs.size()))) return rc;
     }
     h->planned = true;
+    if (getenv("NBLS_PLAN_TIMING")) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "nbls_plan: tables %.3f ms, uploads %.3f ms, buffers+rest %.3f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
+    }
     return NBLS_OK;
 }
 
@@ -412,10 +465,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     const size_t cells = (size_t)h->nbands * h->vector_len;
     const int P = h->d_xij ? h->npairs : 1;
     // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272)
-    HIPCHK(h, hipMemsetAsync(h->d_vel, 0, cells * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_baz, 0, cells * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_mdccm, 0, cells * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_sig, 0, cells * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_res, 0, h->res_bytes, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_z, 0, 2 * cells * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_lag, 0, cells * P * sizeof(int32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_cmax, 0, cells * P * sizeof(double), h->stream));
@@ -432,8 +482,8 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     return NBLS_OK;
 }
 
-int nbls_sync(nbls_handle* h) {
-    if (!h) return NBLS_ERR_ARG;
+// Wait for the handle's stream and, when profiling is on, turn the events of the last pass into timings.
+static int finish_pass(nbls_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->prof && h->ev_valid) {
@@ -458,17 +508,25 @@ int nbls_sync(nbls_handle* h) {
     return NBLS_OK;
 }
 
+int nbls_sync(nbls_handle* h) {
+    if (!h) return NBLS_ERR_ARG;
+    return finish_pass(h);
+}
+
 int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* sigma_tau, int32_t* nwin,
                int32_t* lag, double* cmax, uint8_t* weights, double* z) {
     if (!h) return NBLS_ERR_ARG;
     if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_fetch: no plan");
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    { const int rc = finish_pass(h); if (rc) return rc; }
     const size_t cells = (size_t)h->nbands * h->vector_len;
-    if (vel) HIPCHK(h, hipMemcpy(vel, h->d_vel, cells * sizeof(double), hipMemcpyDeviceToHost));
-    if (baz) HIPCHK(h, hipMemcpy(baz, h->d_baz, cells * sizeof(double), hipMemcpyDeviceToHost));
-    if (mdccm) HIPCHK(h, hipMemcpy(mdccm, h->d_mdccm, cells * sizeof(double), hipMemcpyDeviceToHost));
-    if (sigma_tau) HIPCHK(h, hipMemcpy(sigma_tau, h->d_sig, cells * sizeof(double), hipMemcpyDeviceToHost));
+    const double* dg[4] = {h->d_vel, h->d_baz, h->d_mdccm, h->d_sig};
+    double* hg[4] = {vel, baz, mdccm, sigma_tau};
+    if (vel && baz == vel + cells && mdccm == baz + cells && sigma_tau == mdccm + cells) {
+        HIPCHK(h, hipMemcpy(vel, h->d_vel, 4 * cells * sizeof(double), hipMemcpyDeviceToHost));   // caller's grids are one block too
+    } else {
+        for (int g = 0; g < 4; ++g)
+            if (hg[g]) HIPCHK(h, hipMemcpy(hg[g], dg[g], cells * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (nwin) memcpy(nwin, h->nwin.data(), h->nbands * sizeof(int32_t));
     if (lag) HIPCHK(h, hipMemcpy(lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (cmax) HIPCHK(h, hipMemcpy(cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost));
@@ -495,6 +553,25 @@ int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid) {
     ptrs[0] = h->d_vel; ptrs[1] = h->d_baz; ptrs[2] = h->d_mdccm; ptrs[3] = h->d_sig; ptrs[4] = h->d_nwin;
     if (bytes_per_grid) *bytes_per_grid = (int64_t)h->nbands * h->vector_len * (int64_t)sizeof(double);
     return NBLS_OK;
+}
+
+int nbls_result_layout(nbls_handle* h, int64_t* out4) {
+    if (!h || !out4) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_result_layout: no plan");
+    out4[0] = (int64_t)h->nbands * h->vector_len;
+    out4[1] = h->mask_bytes;
+    out4[2] = (int64_t)h->res_bytes;
+    out4[3] = (int64_t)(4 * sizeof(double)) * out4[0];      // byte offset of the mask
+    return NBLS_OK;
+}
+
+int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes) {
+    if (!h || !out) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_fetch_packed: no plan");
+    if (nbytes != (int64_t)h->res_bytes) return fail(h, NBLS_ERR_ARG, "nbls_fetch_packed: size does not match nbls_result_layout");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, h->stream));   // ordered after the pass
+    return finish_pass(h);
 }
 
 int nbls_set_profiling(nbls_handle* h, int32_t on) {

@@ -1,0 +1,268 @@
+// _nbls_host: CPython helpers for the host side of narrow_band_least_squares().
+//
+// The reference returns, for LTS runs, a dictionary with one entry per (band, window) that dropped
+// an element pair: key '<band:02d>_' + str(window time) -> 1-based element numbers of both members of
+// every zero-weight pair (lts_array's `stdict`, merged at narrow_band_least_squares.py:114-124).  At
+// cfg-3 that is ~5*10^4 string keys and small arrays per call; building them with per-window Python
+// calls costs more than the whole GPU pass.  These two functions build the same objects in one C++ pass:
+//
+//   time_keys(t (B, VL) float64, nwin (B,) int64, prefixes list[str] | None) -> flat list[str]
+//       prefix[b] + repr(float(t[b, w])) for w < nwin[b], bands in order.  repr() is Python's
+//       float repr (shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16, else exponent
+//       form), which is also the text str(numpy.float64) gives.  Needs no GPU result: the band loop calls
+//       it while the pass is running.
+//   build_stdict(mask (B, VL, MB) uint8, nwin (B,) int64, pair_idx (P, 2) int32, nchans, keys flat list)
+//       -> dict, entries in (band, window) order, 'size' right after the first band's entries (the
+//       insertion order of the reference's merge loop).  Windows that dropped the SAME set of pairs
+//       share ONE read-only array object (the reference makes a fresh array per window; the values are
+//       equal, an in-place write raises instead of aliasing) — creating ~5*10^4 tiny arrays costs as
+//       much host time as the GPU pass.
+//
+// engine.py holds pure-Python equivalents (used when this module is not built; tests compare the two).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// Python's repr(float) into out (>= 32 bytes); returns the length.
+int py_float_repr(double x, char* out) {
+    if (x != x) { memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) {
+        if (x < 0) { memcpy(out, "-inf", 4); return 4; }
+        memcpy(out, "inf", 3); return 3;
+    }
+    if (x == 0.0) {
+        if (std::signbit(x)) { memcpy(out, "-0.0", 4); return 4; }
+        memcpy(out, "0.0", 3); return 3;
+    }
+    char buf[48];
+    const auto r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX, shortest round trip
+    const char* p = buf;
+    const char* end = r.ptr;
+    char* o = out;
+    if (*p == '-') { *o++ = '-'; ++p; }
+    char digits[24];
+    int nd = 0;
+    while (p < end && *p != 'e') {
+        if (*p != '.') digits[nd++] = *p;
+        ++p;
+    }
+    ++p;                                    // 'e'
+    int esign = 1;
+    if (*p == '+') ++p; else if (*p == '-') { esign = -1; ++p; }
+    int e10 = 0;
+    while (p < end) e10 = e10 * 10 + (*p++ - '0');
+    const int decpt = esign * e10 + 1;      // position of the decimal point relative to the digit string
+    if (decpt > 16 || decpt < -3) {         // exponent form: d[.ddd]e+XX (at least two exponent digits)
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        int ex = decpt - 1;
+        if (ex < 0) { *o++ = '-'; ex = -ex; } else *o++ = '+';
+        char eb[8];
+        int ne = 0;
+        do { eb[ne++] = (char)('0' + ex % 10); ex /= 10; } while (ex);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) *o++ = eb[--ne];
+    } else if (decpt <= 0) {                // 0.000ddd
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -decpt; ++i) *o++ = '0';
+        memcpy(o, digits, nd); o += nd;
+    } else if (decpt >= nd) {               // ddd000.0
+        memcpy(o, digits, nd); o += nd;
+        for (int i = nd; i < decpt; ++i) *o++ = '0';
+        *o++ = '.'; *o++ = '0';
+    } else {                                // dd.ddd
+        memcpy(o, digits, decpt); o += decpt;
+        *o++ = '.';
+        memcpy(o, digits + decpt, nd - decpt); o += nd - decpt;
+    }
+    return (int)(o - out);
+}
+
+PyArrayObject* as_array(PyObject* obj, int typenum, int ndim, const char* what) {
+    PyArrayObject* a = (PyArrayObject*)PyArray_FROM_OTF(obj, typenum, NPY_ARRAY_IN_ARRAY);
+    if (!a) return nullptr;
+    if (PyArray_NDIM(a) != ndim) {
+        PyErr_Format(PyExc_ValueError, "%s must have %d dimensions", what, ndim);
+        Py_DECREF(a);
+        return nullptr;
+    }
+    return a;
+}
+
+PyObject* float_repr(PyObject*, PyObject* arg) {
+    const double x = PyFloat_AsDouble(arg);
+    if (x == -1.0 && PyErr_Occurred()) return nullptr;
+    char buf[40];
+    const int n = py_float_repr(x, buf);
+    return PyUnicode_FromStringAndSize(buf, n);
+}
+
+PyObject* time_keys(PyObject*, PyObject* args) {
+    PyObject *t_obj, *nwin_obj, *prefixes;
+    if (!PyArg_ParseTuple(args, "OOO", &t_obj, &nwin_obj, &prefixes)) return nullptr;
+    PyArrayObject* t = as_array(t_obj, NPY_FLOAT64, 2, "t");
+    if (!t) return nullptr;
+    PyArrayObject* nw = as_array(nwin_obj, NPY_INT64, 1, "nwin");
+    if (!nw) { Py_DECREF(t); return nullptr; }
+    const npy_intp B = PyArray_DIM(t, 0), VL = PyArray_DIM(t, 1);
+    PyObject* out = nullptr;
+    std::vector<std::pair<const char*, Py_ssize_t>> pre;
+    bool ok = PyArray_DIM(nw, 0) == B;
+    if (!ok) PyErr_SetString(PyExc_ValueError, "nwin must have one entry per band");
+    if (ok && prefixes != Py_None) {
+        if (!PyList_Check(prefixes) || PyList_GET_SIZE(prefixes) != B) {
+            PyErr_SetString(PyExc_ValueError, "prefixes must be None or a list with one string per band");
+            ok = false;
+        }
+        for (npy_intp b = 0; ok && b < B; ++b) {
+            Py_ssize_t n = 0;
+            const char* s = PyUnicode_AsUTF8AndSize(PyList_GET_ITEM(prefixes, b), &n);
+            if (!s) ok = false; else pre.emplace_back(s, n);
+        }
+    }
+    if (ok) {
+        const int64_t* nwin = (const int64_t*)PyArray_DATA(nw);
+        const double* tt = (const double*)PyArray_DATA(t);
+        Py_ssize_t total = 0;
+        for (npy_intp b = 0; b < B; ++b) {
+            if (nwin[b] < 0 || nwin[b] > VL) { PyErr_SetString(PyExc_ValueError, "nwin out of range"); ok = false; break; }
+            total += (Py_ssize_t)nwin[b];
+        }
+        if (ok) out = PyList_New(total);
+        if (out) {
+            Py_ssize_t k = 0;
+            std::vector<char> buf(64);
+            for (npy_intp b = 0; b < B && out; ++b) {
+                const Py_ssize_t pl = pre.empty() ? 0 : pre[b].second;
+                if ((size_t)pl + 40 > buf.size()) buf.resize(pl + 64);
+                if (pl) memcpy(buf.data(), pre[b].first, pl);
+                for (int64_t w = 0; w < nwin[b]; ++w) {
+                    const int n = py_float_repr(tt[b * VL + w], buf.data() + pl);
+                    PyObject* s = PyUnicode_FromStringAndSize(buf.data(), pl + n);
+                    if (!s) { Py_CLEAR(out); break; }
+                    (void)PyObject_Hash(s);          // cached in the string: the dictionary insert later skips it
+                    PyList_SET_ITEM(out, k++, s);
+                }
+            }
+        }
+    }
+    Py_DECREF(t);
+    Py_DECREF(nw);
+    return out;
+}
+
+PyObject* build_stdict(PyObject*, PyObject* args) {
+    PyObject *mask_obj, *nwin_obj, *pair_obj, *keys;
+    long nchans;
+    if (!PyArg_ParseTuple(args, "OOOlO", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys)) return nullptr;
+    if (!PyList_Check(keys)) { PyErr_SetString(PyExc_TypeError, "keys must be a flat list of strings"); return nullptr; }
+    PyArrayObject* mask = as_array(mask_obj, NPY_UINT8, 3, "mask");
+    if (!mask) return nullptr;
+    PyArrayObject* nw = as_array(nwin_obj, NPY_INT64, 1, "nwin");
+    PyArrayObject* pr = nw ? as_array(pair_obj, NPY_INT32, 2, "pair_idx") : nullptr;
+    PyObject* d = nullptr;
+    PyObject* size_obj = nullptr;
+    if (nw && pr) {
+        const npy_intp B = PyArray_DIM(mask, 0), VL = PyArray_DIM(mask, 1), MB = PyArray_DIM(mask, 2);
+        const npy_intp P = PyArray_DIM(pr, 0);
+        const int64_t* nwin = (const int64_t*)PyArray_DATA(nw);
+        const int32_t* pair = (const int32_t*)PyArray_DATA(pr);
+        const uint8_t* m = (const uint8_t*)PyArray_DATA(mask);
+        bool ok = PyArray_DIM(pr, 1) == 2 && PyArray_DIM(nw, 0) == B && MB == (P + 7) / 8;
+        Py_ssize_t total = 0;
+        for (npy_intp b = 0; ok && b < B; ++b) {
+            if (nwin[b] < 0 || nwin[b] > VL) ok = false;
+            total += (Py_ssize_t)nwin[b];
+        }
+        if (!ok || PyList_GET_SIZE(keys) != total) {
+            PyErr_SetString(PyExc_ValueError, "build_stdict: inconsistent shapes (mask / nwin / pair_idx / keys)");
+        } else {
+            d = PyDict_New();
+            size_obj = PyLong_FromLong(nchans);
+            std::vector<int32_t> dropped((size_t)P);
+            std::unordered_map<std::string, PyObject*> patterns;     // mask bytes -> shared value array (owned)
+            std::string pat((size_t)MB, '\0');
+            const uint8_t* last = nullptr;                            // run of equal masks: skip the lookup
+            PyObject* last_arr = nullptr;
+            Py_ssize_t k = 0;
+            for (npy_intp b = 0; b < B && d; ++b) {
+                for (int64_t w = 0; w < nwin[b] && d; ++w, ++k) {
+                    const uint8_t* mm = m + ((size_t)b * VL + (size_t)w) * MB;
+                    PyObject* arr = nullptr;
+                    if (last && memcmp(last, mm, (size_t)MB) == 0) {
+                        arr = last_arr;
+                    } else {
+                        int c = 0;
+                        for (npy_intp by = 0; by < MB; ++by) {
+                            unsigned int z = (~(unsigned int)mm[by]) & 0xffu;          // zero-weight pairs of this byte
+                            if (by == MB - 1 && (P & 7)) z &= (1u << (P & 7)) - 1u;     // bits beyond P are padding
+                            pat[(size_t)by] = (char)z;
+                            while (z) {
+                                const int bit = __builtin_ctz(z);
+                                z &= z - 1;
+                                dropped[c++] = (int32_t)(8 * by + bit);
+                            }
+                        }
+                        if (c) {
+                            auto it = patterns.find(pat);
+                            if (it != patterns.end()) {
+                                arr = it->second;
+                            } else {
+                                npy_intp dims[1] = {2 * c};
+                                arr = PyArray_SimpleNew(1, dims, NPY_INT32);
+                                if (!arr) { Py_CLEAR(d); break; }
+                                int32_t* a = (int32_t*)PyArray_DATA((PyArrayObject*)arr);
+                                for (int i = 0; i < c; ++i) {
+                                    a[i] = pair[2 * dropped[i]] + 1;
+                                    a[c + i] = pair[2 * dropped[i] + 1] + 1;
+                                }
+                                PyArray_CLEARFLAGS((PyArrayObject*)arr, NPY_ARRAY_WRITEABLE);
+                                patterns.emplace(pat, arr);
+                            }
+                        }
+                        last = mm;
+                        last_arr = arr;
+                    }
+                    if (!arr) continue;                 // nothing dropped in this window: no entry
+                    if (PyDict_SetItem(d, PyList_GET_ITEM(keys, k), arr)) { Py_CLEAR(d); break; }
+                }
+                if (d && b == 0 && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+            }
+            for (auto& kv : patterns) Py_DECREF(kv.second);
+            if (d && B == 0 && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+        }
+    }
+    Py_XDECREF(size_obj);
+    Py_DECREF(mask);
+    Py_XDECREF(nw);
+    Py_XDECREF(pr);
+    return d;
+}
+
+PyMethodDef methods[] = {
+    {"float_repr", float_repr, METH_O, "repr(float) computed by this module (self-test hook)"},
+    {"time_keys", time_keys, METH_VARARGS, "time_keys(t, nwin, prefixes) -> flat list of key strings"},
+    {"build_stdict", build_stdict, METH_VARARGS, "build_stdict(mask, nwin, pair_idx, nchans, keys) -> dict"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_nbls_host", "host-side helpers of narrow_band_least_squares_amd", -1, methods,
+                      nullptr, nullptr, nullptr, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__nbls_host(void) {
+    import_array();
+    return PyModule_Create(&moddef);
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/nbls.h"
 
@@ -26,6 +27,7 @@ struct nbls_handle {
 
     // ---- trace (HBM resident) ----
     double* d_trace = nullptr;     // [nchans][npts_pad]
+    size_t cap_trace = 0;
     int nchans = 0;
     int64_t npts = 0, npts_pad = 0;
     double fs = 0.0;
@@ -69,13 +71,28 @@ struct nbls_handle {
     size_t cap_cstate2 = 0;
     int32_t* d_lag = nullptr;      // [B][VL][P]
     double* d_cmax = nullptr;      // [B][VL][P]
-    double* d_vel = nullptr;       // [B][VL]
+    // result block, ONE allocation = one D2H copy / one RCCL gather:
+    //   [vel | baz | mdccm | sigma_tau] double[4][B][VL], then the LTS weight bit mask uint8[B][VL][MB],
+    //   MB = ceil(P/8), bit k & 7 of byte k >> 3 = weight of pair k (ceil(P/8) bytes per unit)
+    unsigned char* d_res = nullptr;
+    size_t cap_res = 0, res_bytes = 0;
+    size_t reserve_res = 0;        // minimum allocation of the result block (nbls_reserve_results: equal gather blocks)
+    // ---- RCCL gather (comm.hip) ----
+    void* comm = nullptr;          // ncclComm_t
+    int comm_world = 1, comm_rank = 0;
+    unsigned char* d_gather = nullptr;   // [world][block_bytes] receive side
+    size_t cap_gather = 0;
+    int64_t gather_status = 0;     // host copy of the status word while its H2D copy is in flight
+    int mask_bytes = 0;            // MB
+    double* d_vel = nullptr;       // [B][VL]   (views into d_res)
     double* d_baz = nullptr;
     double* d_mdccm = nullptr;
     double* d_sig = nullptr;
+    uint8_t* d_mask = nullptr;     // [B][VL][MB] (view into d_res)
     double* d_z = nullptr;         // [B][VL][2]
-    uint8_t* d_wts = nullptr;      // [B][VL][P]
-    size_t cap_filt = 0, cap_cstate = 0, cap_res = 0, cap_units = 0, cap_bands = 0;
+    uint8_t* d_wts = nullptr;      // [B][VL][P] one byte per pair (kernel-side form; packed into d_mask after the solve)
+    size_t cap_filt = 0, cap_cstate = 0, cap_lag = 0, cap_cmax = 0, cap_z = 0, cap_wts = 0;
+    std::unordered_map<const void*, size_t> caps;   // capacities of the small plan tables, keyed by the address of the pointer member
 
     // ---- int8 screening correlator (xcorr_screen.hip) ----
     int8_t* d_qbuf = nullptr;      // [batch][N][2][WP]
@@ -111,6 +128,7 @@ hipError_t nbls_launch_filter(nbls_handle* h);
 hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
+hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
 bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl);
 hipError_t nbls_launch_xcorr_screen(nbls_handle* h);

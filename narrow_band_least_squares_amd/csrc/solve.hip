@@ -1649,7 +1649,41 @@ size_t lts_lds_bytes(int P, int S, bool absr) {
 
 hipError_t nbls_launch_solve(nbls_handle* h) { return nbls_launch_solve_range(h, 0, h->nunits, h->stream); }
 
+// LTS weights u8[B][VL][P] -> bit mask u8[B][VL][MB] in the result block (bit k & 7 of byte k >> 3 = pair k).
+// One thread per (unit, mask byte).  Rows of windows that were not computed stay zero (memset by execute).
+__global__ __launch_bounds__(256) void pack_weights_kernel(const uint8_t* wts, uint8_t* mask, const int32_t* unit_band,
+                                                           const int32_t* unit_win, int vector_len, int P, int MB, int u0,
+                                                           int nunits) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= nunits * MB) return;
+    const int ul = item / MB, mb = item - ul * MB;
+    const int u = u0 + ul;
+    const int64_t o = (int64_t)unit_band[u] * vector_len + unit_win[u];
+    const uint8_t* w = wts + o * P + 8 * mb;
+    const int n = P - 8 * mb < 8 ? P - 8 * mb : 8;
+    unsigned int m = 0;
+    for (int k = 0; k < n; ++k) m |= (unsigned int)(w[k] != 0) << k;
+    mask[o * MB + mb] = (uint8_t)m;
+}
+
+static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
+
+hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st) {
+    if (nu <= 0) return hipSuccess;
+    const int MB = h->mask_bytes;
+    const int64_t items = nu * MB;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, h->d_wts, h->d_mask,
+                       h->d_unit_band, h->d_unit_win, h->vector_len, h->npairs, MB, (int)u0, (int)nu);
+    return hipGetLastError();
+}
+
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st) {
+    hipError_t e = solve_range_impl(h, u0, nu, st);
+    if (e != hipSuccess) return e;
+    return nbls_launch_pack_weights(h, u0, nu, st);
+}
+
+static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st) {
     if (nu <= 0) return hipSuccess;
     SArgs a{};
     a.u0 = (int)u0;

@@ -1,24 +1,26 @@
-"""Band sharding across the GPUs of one node (one process per GPU, ``torch.distributed``;
-backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests).
+"""Sharding of one call over the GPUs of a node, and the ONE RCCL operation that collects the results.
 
-Bands are independent units of work — this is exactly how the reference parallelises
-(joblib over bands, narrow_band_least_squares.py:285) — so there is no data-path collective:
-each rank runs the whole hot path for its own bands and ONE all-gather of the padded result
-grids at the end puts every band on every rank.  torch is plumbing here (process group and
-the collective); no kernel of the path runs through it.
+Bands are independent units of work — exactly how the reference parallelises (joblib over bands,
+narrow_band_least_squares.py:285) — so there is no data-path collective: every GPU runs the whole hot
+path for its own bands (or, with fewer bands than GPUs, for its slice of every band's windows) and one
+grouped RCCL operation inside ``libnbls_hip.so`` (``nbls_comm_gather``: grouped send/recv to a root, or
+an all-gather) moves the result blocks over xGMI.  No PyTorch: the communicator lives in the library.
+
+Two ways to drive several GPUs, chosen from the environment:
+
+* one process, all GPUs (default when more than one device is visible and no launcher set a rank):
+  one library handle per device, ``ncclCommInitAll``, per-device host threads only to queue the work;
+* one process per GPU (``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` set by ``torch.distributed.run``,
+  ``mpirun`` or anything else): ``ncclCommInitRank``; the 128-byte communicator id goes from rank 0 to
+  the others over a TCP socket on ``MASTER_ADDR`` (port ``NBLS_COMM_PORT``, default ``MASTER_PORT`` + 73).
 """
+import ctypes as C
+import os
+import socket
+import threading
+import time
+
 import numpy as np
-
-
-def dist_info():
-    """(rank, world_size, backend) of the default process group, or (0, 1, None)."""
-    try:
-        import torch.distributed as td
-    except Exception:
-        return 0, 1, None
-    if td.is_available() and td.is_initialized():
-        return td.get_rank(), td.get_world_size(), td.get_backend()
-    return 0, 1, None
 
 
 def band_costs(npts, fs, winlens, winover, npairs):
@@ -45,78 +47,131 @@ def shard_bands(costs, world):
     return [sorted(x) for x in out]
 
 
-class _DevArray:
-    """Expose a raw device pointer through ``__cuda_array_interface__`` so that torch can wrap
-    HBM owned by libnbls_hip.so without a copy."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr,
-                                         'data': (int(ptr), False), 'version': 2, 'strides': None}
-
-
-def all_gather_arrays(arr, device_index=None):
-    """All-gather one equal-shaped numpy array per rank -> list of numpy arrays (rank order)."""
-    import torch
-    import torch.distributed as td
-    rank, world, backend = dist_info()
-    if backend is None:
-        return [arr]
-    t = torch.from_numpy(np.ascontiguousarray(arr))
-    if backend == 'nccl':
-        t = t.cuda(device_index if device_index is not None else torch.cuda.current_device())
-    outs = [torch.empty_like(t) for _ in range(world)]
-    td.all_gather(outs, t)
-    return [o.cpu().numpy() for o in outs]
+def env_rank():
+    """(rank, world, local_rank) as a launcher exported them, else (0, 1, 0)."""
+    try:
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    except ValueError:
+        return 0, 1, 0
+    return (rank, world, local) if world > 1 else (0, 1, 0)
 
 
-def all_gather_device_grid(ptr, shape, dtype=np.float64, device_index=0):
-    """All-gather a result grid straight from HBM (RCCL reads the library's buffer): -> list of
-    numpy arrays, rank order.  Falls back to a staged copy if torch cannot wrap the pointer."""
-    import torch
-    import torch.distributed as td
-    rank, world, backend = dist_info()
-    typestr = np.dtype(dtype).str
-    t = None
-    if backend == 'nccl':
+def visible_devices():
+    """Device indices one process may drive: ``NBLS_DEVICES`` ("0,1,2"), else every HIP device."""
+    env = os.environ.get('NBLS_DEVICES')
+    if env:
+        return [int(x) for x in env.split(',') if x.strip() != '']
+    from ._hip import load_library
+    return list(range(load_library().nbls_device_count()))
+
+
+class Group:
+    """The ranks (= GPUs) one call is sharded over.  ``handles`` are the library handles THIS process
+    drives (all of them in the one-process form, one in the process-per-GPU form); ``ranks`` their ranks."""
+
+    def __init__(self, handles, ranks, world, root):
+        self.handles, self.ranks, self.world, self.root = handles, ranks, world, root
+
+    def gather(self, block_bytes, status=0):
+        """One grouped RCCL operation: -> (world, block_bytes) uint8 array of every rank's block (the last
+        8 bytes of a block are that rank's status word), or None on a process that does not drive the root."""
+        lib = self.handles[0].lib
+        hs = (C.c_void_p * len(self.handles))(*[h._h for h in self.handles])
+        deliver = self.root < 0 or self.root in self.ranks
+        out = np.empty((self.world, block_bytes), dtype=np.uint8) if deliver else None
+        rc = lib.nbls_comm_gather(hs, len(self.handles), self.root, block_bytes, int(status),
+                                  out.ctypes.data if deliver else None, out.nbytes if deliver else 0)
+        self.handles[0]._chk(rc)
+        return out
+
+
+_groups = {}
+_group_override = None       # tests install a stand-in here (CPU rehearsal of the host logic)
+
+
+def _exchange_unique_id(lib, rank, world, timeout=300.0):
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ.get('NBLS_COMM_PORT', str(int(os.environ.get('MASTER_PORT', '29500')) + 73)))
+    if rank == 0:
+        uid = (C.c_char * 128)()
+        rc = lib.nbls_comm_unique_id(uid, 128)
+        if rc != 0:
+            raise RuntimeError('RCCL is not available (nbls_comm_unique_id -> %d)' % rc)
+        payload = bytes(uid)
+        with socket.create_server(('', port)) as srv:
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(payload)
+        return payload
+    deadline = time.time() + timeout
+    while True:
         try:
-            t = torch.as_tensor(_DevArray(ptr, shape, typestr), device='cuda:%d' % device_index)
-        except Exception:
-            t = None
-    if t is None:
-        raise RuntimeError('device-pointer gather needs the nccl backend and __cuda_array_interface__ support')
-    outs = [torch.empty_like(t) for _ in range(world)]
-    td.all_gather(outs, t)
-    return [o.cpu().numpy() for o in outs]
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                buf = b''
+                while len(buf) < 128:
+                    chunk = s.recv(128 - len(buf))
+                    if not chunk:
+                        raise ConnectionError('short read')
+                    buf += chunk
+                return buf
+        except OSError:
+            if time.time() > deadline:
+                raise RuntimeError('rank %d could not fetch the RCCL id from %s:%d' % (rank, addr, port))
+            time.sleep(0.05)
 
 
-def all_gather_device_grids(ptrs, nbytes, shape, device_index=0):
-    """All-gather the four result grids (vel, baz, mdccm, sigma_tau) of every rank with ONE collective
-    when they are one contiguous block in HBM (the library allocates them so), else one per grid.
-    -> list over ranks of (4, *shape) float64 arrays."""
-    import torch
-    import torch.distributed as td
-    rank, world, backend = dist_info()
-    if backend != 'nccl':
-        raise RuntimeError('device-pointer gather needs the nccl backend')
-    cells = int(np.prod(shape))
-    contiguous = all(int(ptrs[i + 1]) - int(ptrs[i]) == nbytes for i in range(3)) and nbytes == cells * 8
-    if not contiguous:
-        per = [all_gather_device_grid(p, shape, np.float64, device_index) for p in ptrs[:4]]
-        return [np.stack([per[g][r] for g in range(4)]) for r in range(world)]
-    t = torch.as_tensor(_DevArray(ptrs[0], (4 * cells,), np.dtype(np.float64).str), device='cuda:%d' % device_index)
-    key = (world, 4 * cells, device_index)
-    bufs = _GATHER_BUFFERS.get(key)
-    if bufs is None:        # device destination + pinned host landing zone, reused by every call of this shape
-        bufs = (torch.empty((world, 4 * cells), dtype=torch.float64, device=t.device),
-                torch.empty((world, 4 * cells), dtype=torch.float64, pin_memory=True))
-        _GATHER_BUFFERS.clear()
-        _GATHER_BUFFERS[key] = bufs
-    out, pinned = bufs
-    td.all_gather_into_tensor(out, t)
-    pinned.copy_(out, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    host = pinned.numpy()
-    return [host[r].reshape((4,) + tuple(shape)).copy() for r in range(world)]
+def get_group():
+    """The Group of this process, or None when a single GPU does the whole call.  Communicators are
+    created once per process and reused."""
+    if _group_override is not None:
+        return _group_override
+    from . import engine
+    rank, world, local = env_rank()
+    if world > 1:                                  # one process per GPU
+        key = ('rank', rank, world, os.getpid())
+        g = _groups.get(key)
+        if g is None:
+            h = engine.get_handle()
+            uid = _exchange_unique_id(h.lib, rank, world)
+            h._chk(h.lib.nbls_comm_init_rank(h._h, uid, world, rank))
+            g = Group([h], [rank], world, root=-1)          # all-gather: every rank returns the results
+            _groups[key] = g
+        return g
+    devs = visible_devices()
+    if len(devs) < 2 and os.environ.get('NBLS_FORCE_DIST_PATH') != '1':
+        return None
+    key = ('all', tuple(devs), os.getpid())
+    g = _groups.get(key)
+    if g is None:
+        hs = [engine.get_handle(d) for d in devs]
+        arr = (C.c_void_p * len(hs))(*[h._h for h in hs])
+        hs[0]._chk(hs[0].lib.nbls_comm_init_all(arr, len(hs)))
+        g = Group(hs, list(range(len(hs))), len(hs), root=0)
+        _groups[key] = g
+    return g
 
 
-_GATHER_BUFFERS = {}
+def run_on_handles(fn, handles):
+    """fn(index, handle) for every local handle — concurrently (the library calls release the GIL) when
+    there are several, so that the GPUs start together.  Exceptions are collected, not raised:
+    -> list of (exception or None) per handle."""
+    errs = [None] * len(handles)
+
+    def work(i):
+        try:
+            fn(i, handles[i])
+        except BaseException as e:      # noqa: BLE001 - reported through the gather's status word
+            errs[i] = e
+    if len(handles) == 1:
+        work(0)
+        return errs
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(handles))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return errs

@@ -2,6 +2,8 @@
 (filter -> xcorr/lag pick -> MdCCM + OLS|LTS for every band x window) and unpacks the result
 grids.  Used by ``ltsva``, ``filter_data``, ``narrow_band_least_squares*`` and ``bench.py``.
 """
+import itertools
+import operator
 import os
 
 import numpy as np
@@ -9,6 +11,11 @@ import numpy as np
 from . import planner
 from ._hip import Handle
 from .stream import start_datenum
+
+try:                                   # C++ helpers for the stdict keys / dictionary (csrc/host_ext.cpp)
+    from . import _nbls_host as _hostext
+except ImportError:                    # not built: the pure-Python equivalents below are used
+    _hostext = None
 
 _handles = {}
 
@@ -48,6 +55,35 @@ def stream_to_array(st):
     return data, fs, start_datenum(getattr(st[0].stats, 'starttime', 0.0))
 
 
+def stream_rows(st):
+    """-> (list of per-channel 1-D float64 arrays — the traces' own buffers when they already are
+    C-contiguous float64 —, fs, start date number).  Nothing is packed: ``Handle.set_trace_rows``
+    uploads every row from where it lies."""
+    nchans = len(st)
+    if nchans == 0:
+        raise ValueError('empty stream')
+    npts = len(st[0].data)
+    fs = float(st[0].stats.sampling_rate)
+    rows = []
+    for tr in st:
+        d = np.asarray(tr.data)
+        if len(d) != npts:
+            raise ValueError('All traces must have the same number of samples.')
+        if d.dtype != np.float64 or not d.flags.c_contiguous:
+            d = np.ascontiguousarray(d, dtype=np.float64)
+        rows.append(d)
+    return rows, fs, start_datenum(getattr(st[0].stats, 'starttime', 0.0))
+
+
+def _shape_of(data):
+    """(nchans, npts) of a 2-D array or of a list of equally long rows."""
+    if isinstance(data, np.ndarray):
+        if data.ndim != 2:
+            raise ValueError('trace must be (nchans, npts)')
+        return data.shape
+    return len(data), len(data[0])
+
+
 def check_elements(nchans, alpha):
     if nchans < 3:
         raise RuntimeError('At least 3 array elements are needed for the least squares estimate.')
@@ -64,10 +100,20 @@ def window_times(t0_datenum, fs, W, inc, nwin):
 
 
 class BandBatch:
-    """Results of one device pass over ``nbands`` bands (arrays are (nbands, vector_len))."""
+    """Results of one device pass over ``nbands`` bands (arrays are (nbands, vector_len)).
+    ``mask`` (nbands, vector_len, ceil(P/8)) is the packed LTS weight mask as the GPU returns it;
+    ``weights`` (nbands, vector_len, P) uint8 is unpacked from it on first use."""
 
     def __init__(self, **kw):
+        self._weights = None
         self.__dict__.update(kw)
+
+    @property
+    def weights(self):
+        if self._weights is None and getattr(self, 'mask', None) is not None and self.lts:
+            P = len(self.pair_idx)
+            self._weights = np.unpackbits(self.mask, axis=-1, bitorder='little')[..., :P]
+        return self._weights
 
 
 def max_bands_per_pass(nchans, npts):
@@ -77,46 +123,20 @@ def max_bands_per_pass(nchans, npts):
     return max(1, int(budget // (8.0 * nchans * (npts + 64))))
 
 
-def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
-            filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
-            want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
-            upload=True, window_slice=None):
-    """Run the hot path for a list of bands on one GPU.
+class Prep:
+    """Host-side plan of a call: everything the GPU pass needs that is computed on the host — window
+    plan, filter design, taper ramps, co-array, FAST-LTS constants — for ALL bands of the call.  A device
+    then runs any subset of the bands (band sharding) or of the windows (window sharding) of it."""
 
-    window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
-    sharding across GPUs); rows outside the slice stay zero, ``nwin``/``t`` describe the whole band.
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
 
-    data (N, npts) raw traces; band_edges [(fmin, fmax), ...]; winlens [seconds per band].
-    prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
-    More bands than fit in HBM at once are processed in consecutive passes."""
-    nchans, npts = data.shape
-    cap = max_bands_per_pass(nchans, npts)
-    if len(band_edges) > cap and not prefiltered:
-        if vector_len is None:
-            vector_len = max(1, max(planner.window_plan(npts, fs, wl, winover)[2] for wl in winlens))
-        parts = []
-        for b0 in range(0, len(band_edges), cap):
-            parts.append(process(data, fs, t0_datenum, rij, band_edges[b0:b0 + cap], winlens[b0:b0 + cap], winover,
-                                 alpha, filter_type, filter_order, filter_ripple, vector_len, device, xcorr_impl,
-                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0, window_slice))
-        first = parts[0]
 
-        def cat(name):
-            vals = [getattr(p, name) for p in parts]
-            return None if vals[0] is None else np.concatenate(vals, axis=0)
-        return BandBatch(vel=cat('vel'), baz=cat('baz'), mdccm=cat('mdccm'), sigma_tau=cat('sigma_tau'),
-                         nwin=cat('nwin'), t=cat('t'), weights=cat('weights'), lag=cat('lag'), cmax=cat('cmax'),
-                         z=cat('z'), sos=[s for p in parts for s in p.sos], W=cat('W'), inc=cat('inc'),
-                         pair_idx=first.pair_idx, xij=first.xij, nchans=nchans, alpha=alpha, handle=first.handle)
+def prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_type=None, filter_order=None,
+            filter_ripple=None, vector_len=None, prefiltered=False):
     check_elements(nchans, alpha)
     nb = len(band_edges)
-    h = handle if handle is not None else get_handle(device)
-    if upload:
-        h.set_trace(data, fs)
-        xij, pair_idx, xpinv = planner.co_array(rij)
-        h.set_geometry(xij, pair_idx, xpinv)
-    else:
-        xij, pair_idx, xpinv = planner.co_array(rij)
+    xij, pair_idx, xpinv = planner.co_array(rij)
     W = np.empty(nb, dtype=np.int32)
     inc = np.empty(nb, dtype=np.int32)
     nwin = np.empty(nb, dtype=np.int64)
@@ -143,49 +163,190 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         sos = planner.pad_sections(applied)
         tl, tr = planner.taper_ramps(npts)
     lts = planner.lts_plan(xij, alpha) if alpha < 1.0 else None
+    return Prep(nchans=nchans, npts=npts, fs=fs, nbands=nb, xij=xij, pair_idx=pair_idx, xpinv=xpinv, W=W, inc=inc,
+                nwin=nwin, vector_len=int(vector_len), sos=sos, zero_phase=zero_phase, tl=tl, tr=tr, lts=lts,
+                sos_ret=sos_ret, alpha=alpha, npairs=xij.shape[0], mask_bytes=(xij.shape[0] + 7) // 8)
+
+
+def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0):
+    """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
+    None = all) on handle ``h``.  Returns as soon as the kernels are queued."""
+    if upload:
+        if isinstance(data, np.ndarray):
+            h.set_trace(data, prep.fs)
+        else:
+            h.set_trace_rows(data, prep.fs)
+        h.set_geometry(prep.xij, prep.pair_idx, prep.xpinv)
+    idx = np.arange(prep.nbands) if bands is None else np.asarray(bands, dtype=np.int64)
+    sos = None if prep.sos is None else prep.sos[idx]
     if window_slice is not None:
         k, n = window_slice
-        first = (nwin * k) // n
-        h.set_window_ranges(first, (nwin * (k + 1)) // n - first)
+        nw = prep.nwin[idx]
+        first = (nw * k) // n
+        h.set_window_ranges(first, (nw * (k + 1)) // n - first)
+    h.reserve_results(reserve_bytes)
     try:
-        h.plan(sos, zero_phase, tl, tr, W, inc, vector_len, lts=lts, xcorr_impl=xcorr_impl)
+        h.plan(sos, prep.zero_phase, prep.tl, prep.tr, prep.W[idx], prep.inc[idx], prep.vector_len, lts=prep.lts,
+               xcorr_impl=xcorr_impl)
     finally:
         if window_slice is not None:
             h.set_window_ranges(None)
     h.execute()
-    h.sync()
-    out = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_weights=lts is not None, want_z=want_z)
-    t = np.zeros((nb, vector_len))
-    for b in range(nb):
-        t[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
-    return BandBatch(vel=out['vel'], baz=out['baz'], mdccm=out['mdccm'], sigma_tau=out['sigma_tau'],
-                     nwin=nwin.astype(int), t=t, weights=out['weights'], lag=out['lag'],
-                     cmax=out['cmax'], z=out['z'], sos=sos_ret, W=W, inc=inc, pair_idx=pair_idx,
-                     xij=xij, nchans=nchans, alpha=alpha, handle=h)
+
+
+def all_window_times(prep, t0_datenum):
+    t = np.zeros((prep.nbands, prep.vector_len))
+    for b in range(prep.nbands):
+        t[b, :prep.nwin[b]] = window_times(t0_datenum, prep.fs, int(prep.W[b]), int(prep.inc[b]), int(prep.nwin[b]))
+    return t
+
+
+def split_block(block, nbands, vector_len, mask_bytes):
+    """A result block (bytes as the GPU wrote them, see nbls_result_layout) -> (grids (4, B, VL) float64,
+    mask (B, VL, MB) uint8) views."""
+    cells = nbands * vector_len
+    grids = block[:32 * cells].view(np.float64).reshape(4, nbands, vector_len)
+    mask = block[32 * cells:32 * cells + cells * mask_bytes].reshape(nbands, vector_len, mask_bytes)
+    return grids, mask
+
+
+def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
+            filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
+            want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
+            upload=True, window_slice=None, host_overlap=None):
+    """Run the hot path for a list of bands on one GPU.
+
+    window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
+    sharding across GPUs); rows outside the slice stay zero, ``nwin``/``t`` describe the whole band.
+
+    data (N, npts) raw traces — a 2-D array or a list of N rows (uploaded from where they lie);
+    band_edges [(fmin, fmax), ...]; winlens [seconds per band].
+    prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
+    host_overlap: callable(partial BandBatch) run on the host between the asynchronous launch of the
+    pass and the wait for it (filter responses, key strings, ...: host work that hides behind the GPU).
+    More bands than fit in HBM at once are processed in consecutive passes."""
+    nchans, npts = _shape_of(data)
+    cap = max_bands_per_pass(nchans, npts)
+    if len(band_edges) > cap and not prefiltered:
+        if vector_len is None:
+            vector_len = max(1, max(planner.window_plan(npts, fs, wl, winover)[2] for wl in winlens))
+        parts = []
+        for b0 in range(0, len(band_edges), cap):
+            parts.append(process(data, fs, t0_datenum, rij, band_edges[b0:b0 + cap], winlens[b0:b0 + cap], winover,
+                                 alpha, filter_type, filter_order, filter_ripple, vector_len, device, xcorr_impl,
+                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0, window_slice))
+        first = parts[0]
+
+        def cat(name):
+            vals = [getattr(p, name) for p in parts]
+            return None if vals[0] is None else np.concatenate(vals, axis=0)
+        out = BandBatch(vel=cat('vel'), baz=cat('baz'), mdccm=cat('mdccm'), sigma_tau=cat('sigma_tau'),
+                        nwin=cat('nwin'), t=cat('t'), mask=cat('mask'), lag=cat('lag'), cmax=cat('cmax'),
+                        z=cat('z'), sos=[s for p in parts for s in p.sos], W=cat('W'), inc=cat('inc'),
+                        pair_idx=first.pair_idx, xij=first.xij, nchans=nchans, alpha=alpha, handle=first.handle,
+                        lts=first.lts, fs=fs)
+        if host_overlap is not None:
+            host_overlap(out)
+        return out
+    prep = prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
+                   filter_ripple, vector_len, prefiltered)
+    h = handle if handle is not None else get_handle(device)
+    launch(h, data, prep, upload=upload, window_slice=window_slice, xcorr_impl=xcorr_impl)
+    # asynchronous from here: the host work below hides behind the pass
+    res = BandBatch(vel=None, baz=None, mdccm=None, sigma_tau=None, nwin=prep.nwin.astype(int),
+                    t=all_window_times(prep, t0_datenum), mask=None, lag=None, cmax=None, z=None, sos=prep.sos_ret,
+                    W=prep.W, inc=prep.inc, pair_idx=prep.pair_idx, xij=prep.xij, nchans=nchans, alpha=alpha, handle=h,
+                    lts=prep.lts is not None, fs=fs)
+    if host_overlap is not None:
+        host_overlap(res)
+    out = h.fetch_packed()                        # waits for the pass; ONE D2H copy (grids + weight mask)
+    res.vel, res.baz, res.mdccm, res.sigma_tau, res.mask = (out['vel'], out['baz'], out['mdccm'], out['sigma_tau'],
+                                                            out['mask'])
+    if want_lag or want_cmax or want_z:
+        ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
+        res.lag, res.cmax, res.z = ext['lag'], ext['cmax'], ext['z']
+    return res
+
+
+def time_keys(t, nwin, prefixes=None):
+    """The ``stdict`` key text of every (band, window): prefix + ``str(numpy.float64 time)`` — repr of a
+    Python float is the same shortest round-trip text.  -> ONE flat list of strings, bands in order,
+    ``nwin[b]`` keys per band.  Needs no GPU result, so the band loop computes it while the pass is running."""
+    if _hostext is not None:
+        return _hostext.time_keys(np.ascontiguousarray(t, dtype=np.float64), np.ascontiguousarray(nwin, dtype=np.int64),
+                                  None if prefixes is None else list(prefixes))
+    return _py_time_keys(t, nwin, prefixes)
+
+
+def _py_time_keys(t, nwin, prefixes=None):
+    out = []
+    for b in range(len(nwin)):
+        p = '' if prefixes is None else prefixes[b]
+        reps = map(repr, np.asarray(t[b, :int(nwin[b])], dtype=np.float64).tolist())
+        out.extend([p + s for s in reps] if p else reps)
+    return out
+
+
+def stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
+    """lts_array's dropped-element dictionary for ALL bands of a pass from the packed weight mask
+    (B, VL, ceil(P/8)): key (``keys[b][w]``, see ``time_keys``) -> 1-based element numbers of both
+    members of every zero-weight pair (first members, then second members), only for windows that
+    dropped something; ``'size'`` -> number of elements.  Entries are inserted in (band, window) order as
+    the reference's loops do (narrow_band_least_squares.py:114-124; ``'size'`` therefore sits right after
+    the first band's entries).
+
+    Windows that dropped the SAME set of pairs share ONE read-only array (the reference makes a fresh
+    array per window; the values are equal, and an in-place write raises instead of aliasing): creating
+    ~5*10^4 tiny arrays per call costs as much host time as the whole GPU pass.  With the C++ helper
+    module built, one C++ pass does the work; the NumPy form below is its equivalent."""
+    if _hostext is not None:
+        return _hostext.build_stdict(np.ascontiguousarray(mask, dtype=np.uint8), np.ascontiguousarray(nwin, dtype=np.int64),
+                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys)
+    return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys)
+
+
+def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
+    pair_idx = np.asarray(pair_idx)
+    P = len(pair_idx)
+    B, VL, MB = mask.shape
+    nwin = np.asarray(nwin, dtype=np.int64)
+    valid = np.arange(VL)[None, :] < nwin[:, None]
+    m = mask[valid]                                              # (U, MB), (band, window) order
+    full = np.packbits(np.ones(P, dtype=np.uint8), bitorder='little')
+    hit = ((m & full[None, :]) != full[None, :]).any(axis=1)
+    stdict = {}
+    n = int(np.count_nonzero(hit))
+    if n:
+        sel = np.ascontiguousarray(m[hit])
+        if MB <= 8:                                              # pattern code of every window
+            code = np.zeros(n, dtype=np.uint64)
+            for i in range(MB):
+                code |= sel[:, i].astype(np.uint64) << np.uint64(8 * i)
+        else:
+            code = sel.view(np.dtype((np.void, MB))).ravel()
+        _, first, inv = np.unique(code, return_index=True, return_inverse=True)
+        one = (pair_idx[:1, 0] + 1).dtype
+        pats = []
+        for row in np.unpackbits(sel[first], axis=1, bitorder='little')[:, :P]:
+            cols = np.nonzero(row == 0)[0]
+            arr = np.concatenate((pair_idx[cols, 0] + 1, pair_idx[cols, 1] + 1)).astype(one, copy=False)
+            arr.flags.writeable = False
+            pats.append(arr)
+        pieces = operator.itemgetter(*inv.ravel().tolist())(pats) if n > 1 else (pats[0],)
+        items = zip(itertools.compress(keys, hit.tolist()), pieces)
+        # key order of the reference's merge loop: the first band's time keys, 'size', then the other bands
+        stdict = dict(itertools.islice(items, int(np.count_nonzero(hit[:int(nwin[0])]))))
+        stdict['size'] = nchans
+        stdict.update(items)
+    stdict['size'] = nchans
+    return stdict
 
 
 def stdict_from_weights(weights_row, nwin, t_row, pair_idx, nchans, prefix=''):
-    """lts_array's dropped-element dictionary for one band: key ``str(t)`` -> 1-based element
-    numbers of both members of every zero-weight pair (first members, then second members);
-    ``'size'`` -> number of elements.  ``prefix`` is put in front of every time key (the band prefix of
-    narrow_band_least_squares.py:114-124).  Vectorised: one pass over the weight grid, the values are
-    slices of one array (a 6 h / 48 band run has ~5*10^4 entries)."""
-    stdict = {}
+    """Single-band form of ``stdict_from_mask`` taking unpacked weights (nwin.., P) uint8 and the window
+    times: key ``prefix + str(t)`` (``prefix`` = the band prefix of narrow_band_least_squares.py:114-124)."""
     nwin = int(nwin)
-    rows, cols = np.nonzero(np.asarray(weights_row[:nwin]) == 0)
-    if len(rows):
-        pair_idx = np.asarray(pair_idx)
-        counts = np.bincount(rows, minlength=nwin)
-        starts = np.cumsum(counts) - counts
-        local = np.arange(len(rows)) - starts[rows]
-        pos1 = 2 * starts[rows] + local
-        big = np.empty(2 * len(rows), dtype=(pair_idx[:1, 0] + 1).dtype)
-        big[pos1] = pair_idx[cols, 0] + 1
-        big[pos1 + counts[rows]] = pair_idx[cols, 1] + 1
-        nz = np.nonzero(counts)[0]
-        pieces = np.split(big, np.cumsum(2 * counts[nz])[:-1])
-        # repr of a Python float is the text str(numpy.float64) gives (shortest round-trip form)
-        keys = [prefix + repr(x) for x in np.asarray(t_row, dtype=np.float64)[nz].tolist()]
-        stdict = dict(zip(keys, pieces))
-    stdict['size'] = nchans
-    return stdict
+    w = np.asarray(weights_row[:nwin]) != 0
+    mask = np.packbits(w, axis=-1, bitorder='little')[None, :, :]
+    keys = time_keys(np.asarray(t_row, dtype=np.float64)[None, :nwin], [nwin], [prefix] if prefix else None)
+    return stdict_from_mask(mask, [nwin], pair_idx, nchans, keys)

@@ -58,12 +58,12 @@ def filter_data(st, FILTER_TYPE, FMIN, FMAX, FILTER_ORDER, FILTER_RIPPLE):
     """Band-pass and taper the data on the GPU -> (stf, Fs, sos).  Reference: helpers.py:108-141
     ('butter': zero-phase Butterworth as obspy applies it; 'cheby1': causal Chebyshev-I SOS;
     then a 1 % Hann taper of the whole trace).  ``st`` is not modified."""
-    data, fs, _ = engine.stream_to_array(st)
+    rows, fs, _ = engine.stream_rows(st)
     sos_apply, zero_phase, sos_ret = planner.design_bandpass(FILTER_TYPE, FMIN, FMAX, FILTER_ORDER,
                                                             FILTER_RIPPLE, fs)
     h = engine.get_handle()
-    h.set_trace(data, fs)
-    npts = data.shape[1]
+    h.set_trace_rows(rows, fs)
+    npts = len(rows[0])
     tl, tr = planner.taper_ramps(npts)
     # filter-only plan: one dummy window, no geometry needed (stage mask 1)
     h.plan(sos_apply[None, :, :], zero_phase, tl, tr, [2], [max(1, npts)], 1)

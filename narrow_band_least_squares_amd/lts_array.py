@@ -20,8 +20,8 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
     date numbers, median cross-correlation maximum, dropped-element dictionary (``{}`` for
     OLS), sigma_tau seconds, and the 90 % confidence half-widths of trace velocity (km/s) and
     back-azimuth (degrees; NaN where the direction is undetermined).  ``rij`` (2, N) km overrides the lat/lon geometry."""
-    data, fs, t0 = engine.stream_to_array(st)
-    nchans = data.shape[0]
+    data, fs, t0 = engine.stream_rows(st)
+    nchans = len(data)
     engine.check_elements(nchans, alpha)
     if rij is None:
         rij = get_rij(lat_list, lon_list, nchans)
@@ -30,8 +30,12 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
     if plot_array_coordinates:
         import warnings
         warnings.warn('plot_array_coordinates is not supported on the HIP path; ignored.')
+    def host_side(res):        # key text of the dropped-element dictionary: needs no GPU result
+        if alpha < 1.0:
+            res.keys = engine.time_keys(res.t, res.nwin)
+
     res = engine.process(data, fs, t0, rij, [(None, None)], [window_length], window_overlap, alpha,
-                         prefiltered=True, want_z=True)
+                         prefiltered=True, want_z=True, host_overlap=host_side)
     n = int(res.nwin[0])
     vel = res.vel[0, :n].copy()
     baz = res.baz[0, :n].copy()
@@ -41,6 +45,6 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
     if alpha == 1.0:
         stdict = {}
     else:
-        stdict = engine.stdict_from_weights(res.weights[0], n, t, res.pair_idx, nchans)
+        stdict = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, nchans, res.keys)
     conf_int_vel, conf_int_baz = confidence_intervals(res.xij, res.z[0, :n], sigma_tau)
     return vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz

@@ -4,8 +4,8 @@ loop and the solver inside it run as ONE batched pass on the GPU.
 
 Reference: narrow_band_least_squares.py:8-127 (serial), :134-218 (``narrow_band_loop``),
 :223-323 (``..._parallel``, joblib over bands).  Here the "parallel" variant shards bands over
-the GPUs of a node when a ``torch.distributed`` process group is active (one process per GPU)
-and gathers the grids once at the end; without a process group it equals the serial call.
+the GPUs of a node and collects the result blocks with one RCCL gather inside the library
+(``dist.py``); with one GPU it equals the serial call.
 """
 import os
 
@@ -58,22 +58,33 @@ def _prefix_stdict(stdict, band_number):
 
 
 def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freqlist, FREQ_BAND_TYPE,
-               freq_resp_list, FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, vector_len, rij=None):
-    """One device pass over the given band indices -> (BandBatch, w rows, h rows)."""
-    data, fs, t0 = engine.stream_to_array(st)
+               freq_resp_list, FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, vector_len, rij=None, want_keys=True,
+               key_prefixes=None):
+    """One device pass over the given band indices -> (BandBatch, w rows, h rows).
+
+    Everything on the host that does not need a GPU result — the filter responses (``sosfreqz``,
+    narrow_band_least_squares.py:78-80), the BT caution (:83-87) and the text of the ``stdict`` time
+    keys — runs while the pass is in flight (``host_overlap`` of ``engine.process``).  The traces are
+    uploaded row by row from the stream's own buffers."""
+    rows, fs, t0 = engine.stream_rows(st)
     if rij is None:
-        rij = get_rij(lat_list, lon_list, data.shape[0])
+        rij = get_rij(lat_list, lon_list, len(rows))
     edges = _band_edges(freqlist, FREQ_BAND_TYPE, bands)
     winlens = [WINLEN_list[ii] for ii in bands]
-    res = engine.process(data, fs, t0, rij, edges, winlens, WINOVER, ALPHA, FILTER_TYPE, FILTER_ORDER,
-                         FILTER_RIPPLE, vector_len=vector_len)
     w_rows = np.zeros((len(bands), len(freq_resp_list)), dtype=complex)
     h_rows = np.zeros((len(bands), len(freq_resp_list)), dtype=complex)
-    for n, ii in enumerate(bands):
-        ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
-        w_rows[n, :] = ww
-        h_rows[n, :] = hh
-        _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
+
+    def host_side(res):
+        for n, ii in enumerate(bands):
+            ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
+            w_rows[n, :] = ww
+            h_rows[n, :] = hh
+            _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
+        if ALPHA < 1.0 and want_keys:
+            res.keys = engine.time_keys(res.t, res.nwin, key_prefixes)
+
+    res = engine.process(rows, fs, t0, rij, edges, winlens, WINOVER, ALPHA, FILTER_TYPE, FILTER_ORDER,
+                         FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side)
     return res, w_rows, h_rows
 
 
@@ -96,16 +107,14 @@ def narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_lis
     bands = list(range(NBANDS))
     res, w_array, h_array = _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freqlist,
                                        FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
-                                       FILTER_RIPPLE, vector_len, rij=rij)
+                                       FILTER_RIPPLE, vector_len, rij=rij,
+                                       key_prefixes=[_band_prefix(ii + 1) for ii in bands])
     num_compute_list = [int(n) for n in res.nwin]
     if ALPHA == 1.0:
         stdict_all = None
         sig_tau_array = res.sigma_tau
     else:
-        stdict_all = {}
-        for n, ii in enumerate(bands):
-            stdict_all.update(engine.stdict_from_weights(res.weights[n], num_compute_list[n], res.t[n], res.pair_idx,
-                                                         res.nchans, prefix=_band_prefix(ii + 1)))
+        stdict_all = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
         sig_tau_array = np.zeros_like(res.sigma_tau)
     return (res.vel, res.baz, res.mdccm, res.t, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
@@ -124,7 +133,7 @@ def narrow_band_loop(ii, freqlist, FREQ_BAND_TYPE, freq_resp_list, st, FILTER_TY
         stdict_times = None
         stdict_elements = None
     else:
-        sd = engine.stdict_from_weights(res.weights[0], int(num_compute), res.t[0], res.pair_idx, res.nchans)
+        sd = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
         temp_array = np.array(list(sd.items()), dtype=object)
         stdict_times = temp_array[:, 0]
         stdict_elements = temp_array[:, 1]
@@ -137,122 +146,104 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
                                        FILTER_RIPPLE, rij=None):
     """Band-parallel variant (reference: narrow_band_least_squares.py:223-323, joblib over bands).
 
-    With an initialised ``torch.distributed`` process group of W ranks (one process per GPU) the
-    bands are partitioned over the ranks by cost, each rank runs its bands on its own GPU, and
-    one all-gather makes the complete 9-tuple available on every rank.  Without a process group
-    this is the single-GPU batched call.  Results are identical either way: no value crosses
-    bands."""
-    rank, world, backend = dist.dist_info()
-    if world == 1 and not (backend is not None and os.environ.get('NBLS_FORCE_DIST_PATH') == '1'):
+    The bands are partitioned over the GPUs of the node by cost (fewer bands than GPUs, or
+    ``NBLS_SHARD=windows``: every GPU takes all bands but one contiguous slice of each band's windows),
+    every GPU runs the whole hot path for its share, and ONE grouped RCCL operation inside the library
+    (``nbls_comm_gather``) collects the result blocks — grids and packed LTS weights together — over
+    xGMI.  Either one process drives all visible GPUs (default; ``NBLS_DEVICES`` selects them), or one
+    process per GPU was started by a launcher that exports ``RANK``/``WORLD_SIZE``/``LOCAL_RANK`` (then
+    every rank returns the complete 9-tuple).  With one GPU this is the batched single-GPU call.  Results
+    are identical in every form: no value crosses bands.  No PyTorch is involved."""
+    group = dist.get_group()
+    if group is None or group.world == 1 and os.environ.get('NBLS_FORCE_DIST_PATH') != '1':
         return narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS, w, h,
                                          freqlist, FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
                                          FILTER_RIPPLE, rij=rij)
-    if NBANDS < world or os.environ.get('NBLS_SHARD') == 'windows':
-        return _parallel_by_windows(rank, world, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS,
-                                    freqlist, FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
-                                    FILTER_RIPPLE, rij)
+    world = group.world
     vector_len = _vector_len(WINLEN_list, WINOVER, st)
-    npts = len(st[0].data)
-    fs = float(st[0].stats.sampling_rate)
-    nchans = len(st)
-    npairs = nchans * (nchans - 1) // 2
-    costs = dist.band_costs(npts, fs, [WINLEN_list[b] for b in range(NBANDS)], WINOVER, npairs)
-    shards = dist.shard_bands(costs, world)
-    mine = shards[rank]
-    maxb = max(1, max(len(s) for s in shards))
-    F = len(freq_resp_list)
-    grids = np.zeros((5, maxb, vector_len))          # vel, baz, mdccm, t, sigma_tau
-    nwin = np.zeros(maxb, dtype=np.int64)
-    resp = np.zeros((2, maxb, F), dtype=complex)
-    wts = np.zeros((maxb, vector_len, npairs), dtype=np.uint8)
-    pair_idx = None
-    if mine:
-        res, w_rows, h_rows = _run_bands(mine, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freqlist,
-                                         FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER,
-                                         FILTER_RIPPLE, vector_len, rij=rij)
-        n = len(mine)
-        grids[0, :n], grids[1, :n], grids[2, :n] = res.vel, res.baz, res.mdccm
-        grids[3, :n], grids[4, :n] = res.t, res.sigma_tau
-        nwin[:n] = res.nwin
-        resp[0, :n], resp[1, :n] = w_rows, h_rows
-        if res.weights is not None:
-            wts[:n] = res.weights
-        pair_idx = res.pair_idx
-    if pair_idx is None:
-        from .planner import pair_table
-        pair_idx = pair_table(nchans)
-    dev = engine.default_device()
-    all_grids = dist.all_gather_arrays(grids, dev)
-    all_nwin = dist.all_gather_arrays(nwin, dev)
-    all_resp = dist.all_gather_arrays(np.ascontiguousarray(resp.view(np.float64)), dev)
-    all_wts = dist.all_gather_arrays(wts, dev) if ALPHA < 1.0 else None
-
-    vel_array = np.zeros((NBANDS, vector_len))
-    baz_array = np.zeros((NBANDS, vector_len))
-    mdccm_array = np.zeros((NBANDS, vector_len))
-    t_array = np.zeros((NBANDS, vector_len))
-    sig_tau_array = np.zeros((NBANDS, vector_len))
-    w_array = np.zeros((NBANDS, F), dtype=complex)
-    h_array = np.zeros((NBANDS, F), dtype=complex)
-    num_compute_list = [0] * NBANDS
-    stdict_all = None if ALPHA == 1.0 else {}
-    per_band_dict = {}
-    for r in range(world):
-        g = all_grids[r]
-        rr = all_resp[r].view(complex)
-        for n, b in enumerate(shards[r]):
-            vel_array[b], baz_array[b], mdccm_array[b], t_array[b] = g[0, n], g[1, n], g[2, n], g[3, n]
-            if ALPHA == 1.0:
-                sig_tau_array[b] = g[4, n]
-            num_compute_list[b] = int(all_nwin[r][n])
-            w_array[b], h_array[b] = rr[0, n], rr[1, n]
-            if ALPHA < 1.0:
-                per_band_dict[b] = engine.stdict_from_weights(all_wts[r][n], num_compute_list[b], t_array[b], pair_idx,
-                                                              nchans, prefix=_band_prefix(b + 1))
-    if ALPHA < 1.0:
-        for b in range(NBANDS):
-            stdict_all.update(per_band_dict[b])
-    return (vel_array, baz_array, mdccm_array, t_array, stdict_all, sig_tau_array, num_compute_list,
-            w_array, h_array)
-
-
-def _parallel_by_windows(rank, world, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, NBANDS, freqlist,
-                         FREQ_BAND_TYPE, freq_resp_list, FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, rij):
-    """Fewer bands than GPUs (octave bands, example.py's 8 bands on a bigger node, ...): every rank takes
-    ALL bands but only its contiguous slice of each band's windows.  The filter runs
-    over the whole trace on every rank (zero-phase filtering is not local in time; it is a few per cent of
-    the work), correlation and solve only over the slice.  Slices are disjoint and unprocessed rows are
-    zero, so the full grids are the sum of the gathered per-rank grids."""
-    vector_len = _vector_len(WINLEN_list, WINOVER, st)
-    data, fs, t0 = engine.stream_to_array(st)
-    nchans = data.shape[0]
-    if rij is None:
-        rij = get_rij(lat_list, lon_list, nchans)
+    rows, fs, t0 = engine.stream_rows(st)
+    nchans, npts = len(rows), len(rows[0])
     bands = list(range(NBANDS))
-    edges = _band_edges(freqlist, FREQ_BAND_TYPE, bands)
-    res = engine.process(data, fs, t0, rij, edges, [WINLEN_list[ii] for ii in bands], WINOVER, ALPHA, FILTER_TYPE,
-                         FILTER_ORDER, FILTER_RIPPLE, vector_len=vector_len, window_slice=(rank, world))
+    status, failure, prep = 0, None, None
+    by_windows = NBANDS < world or os.environ.get('NBLS_SHARD') == 'windows'
+    shards = None
+    try:
+        if rij is None:
+            rij = get_rij(lat_list, lon_list, nchans)
+        edges = _band_edges(freqlist, FREQ_BAND_TYPE, bands)
+        prep = engine.prepare(nchans, npts, fs, rij, edges, [WINLEN_list[ii] for ii in bands], WINOVER, ALPHA,
+                              FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, vector_len)
+    except Exception as e:          # a rank that cannot even plan still takes part in the gather (status word)
+        status, failure = 1, e
+    npairs = nchans * (nchans - 1) // 2
+    unit_bytes = 32 + (npairs + 7) // 8
+    if by_windows:
+        nb_block = NBANDS
+    else:
+        costs = dist.band_costs(npts, fs, [WINLEN_list[b] for b in bands], WINOVER, npairs)
+        shards = dist.shard_bands(costs, world)
+        nb_block = max(1, max(len(sh) for sh in shards))
+    block_bytes = (nb_block * vector_len * unit_bytes + 7) // 8 * 8 + 8       # + the status word
+
+    if status == 0:
+        def start(i, hd):
+            r = group.ranks[i]
+            if by_windows:
+                engine.launch(hd, rows, prep, window_slice=(r, world), reserve_bytes=block_bytes)
+            else:
+                engine.launch(hd, rows, prep, bands=shards[r], reserve_bytes=block_bytes)
+        errs = [e for e in dist.run_on_handles(start, group.handles) if e is not None]
+        if errs:
+            status, failure = 1, errs[0]
+
+    # host work that needs no GPU result, while the passes run
     F = len(freq_resp_list)
     w_array = np.zeros((NBANDS, F), dtype=complex)
     h_array = np.zeros((NBANDS, F), dtype=complex)
-    for n, ii in enumerate(bands):
-        ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
-        w_array[n, :], h_array[n, :] = ww, hh
-        if rank == 0:
-            _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
-    dev = engine.default_device()
-    grids = np.stack((res.vel, res.baz, res.mdccm, res.sigma_tau))
-    total = np.sum(dist.all_gather_arrays(grids, dev), axis=0)
-    num_compute_list = [int(n) for n in res.nwin]
+    t_array = keys = None
+    if status == 0:
+        try:
+            for n, ii in enumerate(bands):
+                ww, hh = signal.sosfreqz(prep.sos_ret[n], freq_resp_list, fs=fs)
+                w_array[n, :], h_array[n, :] = ww, hh
+                if 0 in group.ranks:
+                    _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
+            t_array = engine.all_window_times(prep, t0)
+            if ALPHA < 1.0:
+                keys = engine.time_keys(t_array, prep.nwin, [_band_prefix(ii + 1) for ii in bands])
+        except Exception as e:
+            status, failure = 1, e
+
+    blocks = group.gather(block_bytes, status)          # the ONE collective
+    if failure is not None:
+        raise failure
+    if blocks is None:                                  # this process does not drive the root GPU
+        return None
+    stat = np.ascontiguousarray(blocks[:, -8:]).view(np.int64).ravel()
+    if np.any(stat != 0):
+        raise RuntimeError('narrow_band_least_squares_parallel: rank(s) %s failed' % np.nonzero(stat)[0].tolist())
+
+    MB = prep.mask_bytes
+    if by_windows:
+        # slices are disjoint and rows outside a slice are zero: grids add, masks OR
+        grids = np.zeros((4, NBANDS, vector_len))
+        mask = np.zeros((NBANDS, vector_len, MB), dtype=np.uint8)
+        for r in range(world):
+            g, m = engine.split_block(blocks[r], NBANDS, vector_len, MB)
+            grids += g
+            mask |= m
+    else:
+        grids = np.zeros((4, NBANDS, vector_len))
+        mask = np.zeros((NBANDS, vector_len, MB), dtype=np.uint8)
+        for r in range(world):
+            g, m = engine.split_block(blocks[r], len(shards[r]), vector_len, MB)
+            grids[:, shards[r], :] = g
+            mask[shards[r]] = m
+    num_compute_list = [int(n) for n in prep.nwin]
     if ALPHA == 1.0:
         stdict_all = None
-        sig_tau_array = total[3]
+        sig_tau_array = grids[3]
     else:
-        wts = np.sum(dist.all_gather_arrays(res.weights, dev), axis=0, dtype=np.uint8)
-        # rows outside every slice do not exist (beyond num_compute); inside, exactly one rank wrote 0/1
-        stdict_all = {}
-        for n, ii in enumerate(bands):
-            stdict_all.update(engine.stdict_from_weights(wts[n], num_compute_list[n], res.t[n], res.pair_idx, nchans,
-                                                         prefix=_band_prefix(ii + 1)))
-        sig_tau_array = np.zeros_like(total[3])
-    return (total[0], total[1], total[2], res.t, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)
+        stdict_all = engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys)
+        sig_tau_array = np.zeros((NBANDS, vector_len))
+    return (grids[0], grids[1], grids[2], t_array, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)

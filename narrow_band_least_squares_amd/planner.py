@@ -51,18 +51,26 @@ def _design_cached(filter_type, fmin, fmax, order, ripple, fs):
         nyquist = high - 1.0 > -1e-6
         if nyquist:
             z, p, k = signal.iirfilter(order, low, btype='highpass', ftype='butter', output='zpk')
-        else:
-            if low > 1:
-                raise ValueError('Selected low corner frequency is above Nyquist.')
-            z, p, k = signal.iirfilter(order, [low, high], btype='band', ftype='butter', output='zpk')
-        sos_apply = signal.zpk2sos(z, p, k)
-        sos_ret = signal.iirfilter(order, [fmin, fmax], btype='band', ftype='butter', fs=fs, output='sos')
-        return sos_apply, True, sos_ret, nyquist
+            sos_apply = signal.zpk2sos(z, p, k)
+            sos_ret = signal.iirfilter(order, [fmin, fmax], btype='band', ftype='butter', fs=fs, output='sos')
+            return sos_apply, True, sos_ret, nyquist
+        if low > 1:
+            raise ValueError('Selected low corner frequency is above Nyquist.')
+        # obspy designs on [fmin / (fs/2), fmax / (fs/2)] (zpk -> zpk2sos), helpers.py:128 on [fmin, fmax] with
+        # fs=Fs (SciPy then forms 2*f/fs): the same floating-point numbers (scaling by two is exact), so
+        # the two SOS arrays are bit-identical (tests/test_host.py checks it) and ONE design serves both
+        sos = signal.iirfilter(order, [fmin, fmax], btype='band', ftype='butter', fs=fs, output='sos')
+        return sos, True, sos, nyquist
     if filter_type == 'cheby1':
         sos = signal.iirfilter(order, [fmin, fmax], rp=ripple, btype='band', analog=False,
                                ftype='cheby1', fs=fs, output='sos')
         return sos, False, sos, False
     raise ValueError('unknown FILTER_TYPE %r (expected "butter" or "cheby1")' % (filter_type,))
+
+
+def design_cache_clear():
+    """Forget cached filter designs (bench.py clears them before every timed call)."""
+    _design_cached.cache_clear()
 
 
 def pad_sections(sos_list):
@@ -115,8 +123,8 @@ def lts_h(P, alpha, p=LTS_DIM):
     return int(math.floor(2 * n2 - P + 2 * (P - n2) * alpha))
 
 
-def uniran_subsets(P, n_samples=LTS_N_SAMPLES, p=LTS_DIM):
-    """robustbase LCG (seed*5761+999 mod 65536), seed 0, carried across subsets."""
+@functools.lru_cache(maxsize=64)
+def _uniran_cached(P, n_samples, p):
     seed = 0
     out = np.empty((n_samples, p), dtype=np.int64)
     for s in range(n_samples):
@@ -129,7 +137,14 @@ def uniran_subsets(P, n_samples=LTS_N_SAMPLES, p=LTS_DIM):
                     break
             chosen.append(num)
         out[s] = chosen
+    out.flags.writeable = False
     return out
+
+
+def uniran_subsets(P, n_samples=LTS_N_SAMPLES, p=LTS_DIM):
+    """robustbase LCG (seed*5761+999 mod 65536), seed 0, carried across subsets.  A pure function of
+    the pair count (the sequence is generated once per P and kept)."""
+    return _uniran_cached(int(P), int(n_samples), int(p)).copy()
 
 
 def lts_starts(xs):
@@ -138,13 +153,20 @@ def lts_starts(xs):
     extended until they have rank 2.  (S, 4) int32, -1 padded."""
     P = xs.shape[0]
     if P * (P - 1) // 2 <= LTS_N_SAMPLES:
-        subs = [(i, j) for i in range(P - 1) for j in range(i + 1, P)]
+        subs = np.array([(i, j) for i in range(P - 1) for j in range(i + 1, P)], dtype=np.int64)
     else:
-        subs = [tuple(r) for r in uniran_subsets(P)]
+        subs = uniran_subsets(P)
     out = -np.ones((len(subs), 4), dtype=np.int32)
+    out[:, :2] = subs
     scale = np.max(np.abs(xs)) ** 2
-    for s, sub in enumerate(subs):
-        sub = list(sub)
+    # Gram determinant of every 2-subset at once; only the (rare) rank-deficient ones take the repair loop
+    a, b = xs[subs[:, 0]], xs[subs[:, 1]]
+    g00 = a[:, 0] * a[:, 0] + b[:, 0] * b[:, 0]
+    g01 = a[:, 0] * a[:, 1] + b[:, 0] * b[:, 1]
+    g11 = a[:, 1] * a[:, 1] + b[:, 1] * b[:, 1]
+    suspect = np.nonzero(~(g00 * g11 - g01 * g01 > 1e-9 * scale * scale))[0]      # generous margin over the 1e-12 test below
+    for s in suspect.tolist():
+        sub = list(subs[s])
         nxt = 0
         while True:
             g = xs[sub].T @ xs[sub]
@@ -165,6 +187,13 @@ def _consfactor(m, n):
         return 1.0
     q = norm.ppf((m + n) / (2.0 * n))
     return 1.0 / math.sqrt(1.0 - (2.0 * n) / (m / q) * norm.pdf(q))
+
+
+def _consfactor_table(n):
+    """_consfactor(m, n) for m = 1..n-1 in one vectorised pass (same IEEE operations per element)."""
+    m = np.arange(1, n, dtype=np.float64)
+    q = norm.ppf((m + n) / (2.0 * n))
+    return 1.0 / np.sqrt(1.0 - (2.0 * n) / (m / q) * norm.pdf(q))
 
 
 def _cnp2(p, n, alpha, c500, c875):
@@ -203,8 +232,7 @@ def lts_plan(xij, alpha):
     raw = _consfactor(h, P) * _cnp2(LTS_DIM, P, alpha, _RAW_500, _RAW_875)
     rew = np.ones(P + 1)
     cor = _cnp2(LTS_DIM, P, alpha, _REW_500, _REW_875)
-    for nw in range(1, P):
-        rew[nw] = _consfactor(nw, P) * cor
+    rew[1:P] = _consfactor_table(P) * cor
     return dict(alpha=alpha, h=h, starts=starts, csteps=LTS_CSTEPS, csteps2=LTS_CSTEPS2,
                 ncand=LTS_CANDIDATES, xij_mad=xij_mad, raw_factor=raw, rew_table=rew,
                 quantile=LTS_QUANTILE, zero_scale=LTS_ZERO_SCALE)

@@ -1,5 +1,9 @@
-"""Worker for the GPU test of the band-sharded entry point under the real RCCL backend (one rank on the
-one GPU of the test box; NBLS_FORCE_DIST_PATH=1 takes the sharded code path even for world size 1)."""
+"""Worker for the GPU test of the sharded entry point on the library's own RCCL gather (no PyTorch).
+Runs in its own process because a communicator, once made, lives as long as the process.
+
+  mode 'all'   one process drives every visible GPU (this box: one): ncclCommInitAll + gather to root 0
+  mode 'rank'  process-per-GPU form with a one-rank world: the 128-byte id, ncclCommInitRank, all-gather
+Both must equal the serial call bit for bit, bands- and windows-sharded."""
 import os
 import sys
 
@@ -10,14 +14,21 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch
-    import torch.distributed as td
-    torch.cuda.set_device(0)
-    td.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    mode = sys.argv[1]
     os.environ['NBLS_FORCE_DIST_PATH'] = '1'
     from narrow_band_least_squares_amd import (narrow_band_least_squares, narrow_band_least_squares_parallel,
-                                               synthetic)
-    for name, alpha in (('cfg1', 1.0), ('cfg2', 0.5)):
+                                               synthetic, dist, engine)
+    assert 'torch' not in sys.modules
+    if mode == 'rank':
+        # what dist.get_group() does for WORLD_SIZE > 1, with a world of one
+        import ctypes as C
+        h = engine.get_handle()
+        uid = (C.c_char * 128)()
+        assert h.lib.nbls_comm_unique_id(uid, 128) == 0
+        h._chk(h.lib.nbls_comm_init_rank(h._h, bytes(uid), 1, 0))
+        dist._group_override = dist.Group([h], [0], 1, root=-1)
+    for name, alpha, shard in (('cfg1', 1.0, 'bands'), ('cfg2', 0.5, 'bands'), ('cfg2', 0.75, 'windows')):
+        os.environ['NBLS_SHARD'] = shard
         c = synthetic.build_config(name, 0.1)
         nb = 5
         fr = np.logspace(-2, 1, 40)
@@ -35,8 +46,10 @@ def main():
             assert list(par[4].keys()) == list(ser[4].keys())
             for k in ser[4]:
                 np.testing.assert_array_equal(par[4][k], ser[4][k])
-    print('DIST_GPU_OK')
-    td.destroy_process_group()
+    g = dist.get_group()
+    assert g is not None and g.world == 1 and g.handles[0].lib.nbls_version() >= 200
+    assert 'torch' not in sys.modules
+    print('DIST_GPU_OK', mode)
 
 
 if __name__ == '__main__':

@@ -1,7 +1,12 @@
-"""Worker for the world_size-2 gloo test: runs narrow_band_least_squares_parallel() on every rank
-with the device pass replaced by an oracle-backed stand-in (there is no GPU in the CPU test
-environment), so that what is tested is the host logic of the N>1 path: band partition, padded
-all-gather, reassembly, stdict merge."""
+"""CPU rehearsal of the N>1 host logic of narrow_band_least_squares_parallel(): band / window
+partition, equal-sized result blocks, the status word, reassembly and the stdict merge.
+
+There is no GPU here, so the two library calls of that path are replaced by stand-ins:
+``engine.launch`` computes a rank's share with the CPU oracle and leaves a result block laid out
+exactly as the GPU writes it (nbls_result_layout), and the Group's ``gather`` moves the blocks with a
+gloo all-gather (process-per-GPU form, this file run under torch.distributed.run with 2 ranks) or by
+plain concatenation (one-process form, ``run_single_process`` imported by tests/test_host.py).
+The RCCL gather itself is exercised on the GPU box (tests/test_gpu_parity.py)."""
 import os
 import sys
 
@@ -11,58 +16,100 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nbls_oracle as oracle  # noqa: E402
-from narrow_band_least_squares_amd import engine, planner  # noqa: E402
+from narrow_band_least_squares_amd import dist, engine  # noqa: E402
 import importlib  # noqa: E402
 nbls_mod = importlib.import_module('narrow_band_least_squares_amd.narrow_band_least_squares')
 
 
-def fake_process(data, fs, t0, rij, band_edges, winlens, winover, alpha, filter_type=None, filter_order=None,
-                 filter_ripple=None, vector_len=None, window_slice=None, **kw):
-    nb = len(band_edges)
-    nchans = data.shape[0]
-    xij, pair_idx, _ = planner.co_array(rij)
-    P = xij.shape[0]
-    vel = np.zeros((nb, vector_len)); baz = np.zeros_like(vel); md = np.zeros_like(vel)
-    sig = np.zeros_like(vel); t = np.zeros_like(vel)
-    wts = np.zeros((nb, vector_len, P), dtype=np.uint8)
-    nwin = np.zeros(nb, dtype=int)
-    sos = []
-    for b, (fmin, fmax) in enumerate(band_edges):
-        st = oracle.make_stream(data, fs, starttime=t0)
-        stf, _, s = oracle.filter_data(st, filter_type, fmin, fmax, filter_order, filter_ripple)
-        sos.append(s)
-        out, internals = oracle.ltsva(stf, None, None, winlens[b], winover, alpha, rij=rij, return_internals=True)
-        n = len(out[0])
-        nwin[b] = n
-        vel[b, :n], baz[b, :n], t[b, :n], md[b, :n], sig[b, :n] = out[0], out[1], out[2], out[3], out[5]
-        wts[b, :n] = internals['weights'].T
-        if window_slice is not None:          # keep only this rank's slice of the rows, like the device path
-            k, nsl = window_slice
-            lo, hi = (n * k) // nsl, (n * (k + 1)) // nsl
-            for arr in (vel, baz, md, sig):
-                arr[b, :lo] = 0.0
-                arr[b, hi:] = 0.0
-            wts[b, :lo] = 0
-            wts[b, hi:] = 0
-    return engine.BandBatch(vel=vel, baz=baz, mdccm=md, sigma_tau=sig, nwin=nwin, t=t, weights=wts, sos=sos,
-                            pair_idx=pair_idx, nchans=nchans)
+class FakeHandle:
+    block = None
 
 
-def main():
-    import torch.distributed as td
-    td.init_process_group('gloo')
-    rank = td.get_rank()
-    engine.process = fake_process
-    if len(sys.argv) > 2:
-        os.environ['NBLS_SHARD'] = sys.argv[2]
-    gold = np.load(os.path.join(ROOT, 'tests', 'golden', sys.argv[1] + '.npz'), allow_pickle=False)
+def make_fake_launch(gold, fail_rank=None, rank_of=None):
+    """engine.launch stand-in: the oracle computes the share, the block is left on the fake handle."""
+    edges_all = nbls_mod._band_edges(list(gold['freqlist']), str(gold['band_type']), range(len(gold['num_compute'])))
+
+    def fake_launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0):
+        if fail_rank is not None and rank_of(h) == fail_rank:
+            raise ValueError('injected failure on rank %d' % fail_rank)
+        idx = list(range(prep.nbands)) if bands is None else list(bands)
+        nb, VL, MB, P = len(idx), prep.vector_len, prep.mask_bytes, prep.npairs
+        grids = np.zeros((4, nb, VL))
+        wts = np.zeros((nb, VL, P), dtype=np.uint8)
+        arr = np.array(data)
+        for n, b in enumerate(idx):
+            st = oracle.make_stream(arr, prep.fs)
+            stf, _, _ = oracle.filter_data(st, str(gold['ftype']), edges_all[b][0], edges_all[b][1], 2, 0.01)
+            out, internals = oracle.ltsva(stf, None, None, float(gold['winlens'][b]), 0.5, prep.alpha, rij=gold['rij'],
+                                          return_internals=True)
+            k = len(out[0])
+            lo, hi = 0, k
+            if window_slice is not None:      # only this rank's slice of the rows, like the device path
+                r, nsl = window_slice
+                lo, hi = (k * r) // nsl, (k * (r + 1)) // nsl
+            grids[0, n, lo:hi], grids[1, n, lo:hi] = out[0][lo:hi], out[1][lo:hi]
+            grids[2, n, lo:hi], grids[3, n, lo:hi] = out[3][lo:hi], out[5][lo:hi]
+            wts[n, lo:hi] = internals['weights'].T[lo:hi]
+        mask = np.packbits(wts, axis=-1, bitorder='little')
+        assert mask.shape[-1] == MB
+        h.block = np.frombuffer(grids.tobytes() + mask.tobytes(), dtype=np.uint8)
+        assert reserve_bytes >= len(h.block) + 8
+    return fake_launch
+
+
+def pad_block(h, block_bytes, status):
+    blk = np.zeros(block_bytes, dtype=np.uint8)
+    if h.block is not None:
+        blk[:len(h.block)] = h.block
+    blk[-8:] = np.array([status], dtype=np.int64).view(np.uint8)
+    return blk
+
+
+class LocalGroup:
+    """One process, ``world`` fake devices, gather to root 0."""
+
+    def __init__(self, world):
+        self.handles = [FakeHandle() for _ in range(world)]
+        self.ranks = list(range(world))
+        self.world, self.root = world, 0
+
+    def gather(self, block_bytes, status=0):
+        return np.stack([pad_block(h, block_bytes, status) for h in self.handles])
+
+
+class GlooGroup:
+    """One process per rank, all-gather over gloo."""
+
+    def __init__(self, rank, world):
+        self.handles, self.ranks, self.world, self.root = [FakeHandle()], [rank], world, -1
+
+    def gather(self, block_bytes, status=0):
+        import torch
+        import torch.distributed as td
+        t = torch.from_numpy(pad_block(self.handles[0], block_bytes, status))
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        td.all_gather(outs, t)
+        return np.stack([o.numpy() for o in outs])
+
+
+def call_and_compare(gold, group, expect_failure=False):
     st = oracle.make_stream(gold['data'], float(gold['fs']), starttime=17884.0729166667)
     nb = len(gold['num_compute'])
     fr = gold['freq_resp']
     w = np.zeros(len(fr))
     args = (list(gold['winlens']), 0.5, float(gold['alpha']), st, None, None, nb, w, w, list(gold['freqlist']),
             str(gold['band_type']), fr, str(gold['ftype']), 2, 0.01)
-    got = nbls_mod.narrow_band_least_squares_parallel(*args, rij=gold['rij'])
+    dist._group_override = group
+    try:
+        if expect_failure:
+            try:
+                nbls_mod.narrow_band_least_squares_parallel(*args, rij=gold['rij'])
+            except (ValueError, RuntimeError):
+                return nb
+            raise AssertionError('the injected failure did not surface on this rank')
+        got = nbls_mod.narrow_band_least_squares_parallel(*args, rij=gold['rij'])
+    finally:
+        dist._group_override = None
     exp = oracle.narrow_band_least_squares(*args, rij=gold['rij'])
     assert got[6] == exp[6], (got[6], exp[6])
     for i in (0, 1, 2, 3, 5, 7, 8):
@@ -73,9 +120,31 @@ def main():
         assert list(got[4].keys()) == list(exp[4].keys())
         for k in exp[4]:
             np.testing.assert_array_equal(got[4][k], exp[4][k])
+    return nb
+
+
+def run_single_process(gold_name, mode, world, monkeypatch):
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', gold_name + '.npz'), allow_pickle=False)
+    group = LocalGroup(world)
+    monkeypatch.setattr(engine, 'launch', make_fake_launch(gold))
+    if mode == 'windows':
+        monkeypatch.setenv('NBLS_SHARD', 'windows')
+    return call_and_compare(gold, group)
+
+
+def main():
+    import torch.distributed as td
+    td.init_process_group('gloo')
+    rank, world = td.get_rank(), td.get_world_size()
+    mode = sys.argv[2] if len(sys.argv) > 2 else 'bands'
+    if mode == 'windows':
+        os.environ['NBLS_SHARD'] = 'windows'
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', sys.argv[1] + '.npz'), allow_pickle=False)
+    engine.launch = make_fake_launch(gold, fail_rank=1 if mode == 'fail' else None, rank_of=lambda h: rank)
+    nb = call_and_compare(gold, GlooGroup(rank, world), expect_failure=(mode == 'fail'))
     td.barrier()
     if rank == 0:
-        print('DIST_OK world=%d bands=%d' % (td.get_world_size(), nb))
+        print('DIST_OK world=%d bands=%d mode=%s' % (world, nb, mode))
     td.destroy_process_group()
 
 

@@ -4,6 +4,7 @@ Run with the interpreter the reference's outer loop still works on (numpy < 2, b
 ``dtype='complex_'`` at narrow_band_least_squares.py:58):
 
     /opt/conda/bin/python3.9 tests/golden/make_goldens.py loops
+    /opt/conda/bin/python3.9 tests/golden/make_goldens.py extra     (round-2 additions only)
     python tests/golden/make_goldens.py planners
 
 What comes from the reference's own code: ``helpers.get_freqlist`` / ``get_winlenlist`` /
@@ -152,15 +153,55 @@ def band_loop(name, nchans, npts, fs, fmin, fmax, nbands, band_type, ftype, winl
     print(name, 'vector_len', vl, 'num_compute', ncl, 'stdict entries', len(keys))
 
 
+def txtfile():
+    """Bytes written by the reference's own write_txtfile (helpers.py:161-182) for the grids of the
+    loop_ols_butter_linear golden, and the arrays its read_txtfile (helpers.py:185-235) returns for that
+    file: the product's text I/O is compared with both."""
+    import contextlib
+    import io
+    import tempfile
+    g = np.load(os.path.join(HERE, 'loop_ols_butter_linear.npz'), allow_pickle=False)
+    d = tempfile.mkdtemp() + '/'
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_helpers.write_txtfile(d, 'ref', g['vel'], g['baz'], g['mdccm'], g['t'], g['freqlist'], list(g['num_compute']))
+    text = open(d + 'ref.txt', 'rb').read()
+    open(os.path.join(HERE, 'txtfile_ref.txt'), 'wb').write(text)
+    out = ref_helpers.read_txtfile(d, 'ref')
+    names = ('vel', 'baz', 'mdccm', 't', 'freqlist', 'num_compute', 'nbands', 'fmin', 'fmax')
+    # read_txtfile leaves the row tails uninitialised (np.empty): store them zeroed
+    arrs = {}
+    ncl = np.asarray(out[5])
+    for n, v in zip(names, out):
+        v = np.array(v, dtype=float)
+        if v.ndim == 2:
+            for b in range(v.shape[0]):
+                v[b, ncl[b]:] = 0.0
+        arrs[n] = v
+    np.savez_compressed(os.path.join(HERE, 'txtfile_read.npz'), **arrs)
+    print('txtfile', len(text), 'bytes;', 'read back', arrs['vel'].shape, ncl.tolist())
+
+
+def extra():
+    """Fixtures added in round 2 (same interpreter as `loops`): more than 99 bands — the reference's
+    str(band).zfill(2) prefix becomes three characters, '100_', '101_' (narrow_band_least_squares.py:120) —
+    and the text-file fixtures."""
+    band_loop('loop_lts_101bands', 5, 1600, 20.0, 0.5, 5.0, 101, 'linear', 'butter', 30, 0.5, bad=4)
+    txtfile()
+
+
 if __name__ == '__main__':
     # `planners`: run under the default interpreter (numpy 2.x: np.logspace differs from numpy 1.26 in
     # the last bit, and the planners do import there); `loops`: needs numpy < 2 (see the docstring).
     what = sys.argv[1:] or ['planners', 'loops']
     if 'planners' in what:
         planners()
+    if 'extra' in what:
+        extra()
     if 'loops' not in what:
         sys.exit(0)
     band_loop('loop_ols_cheby1_adaptive', 8, 24001, 20.0, 0.1, 5.0, 8, 'log', 'cheby1', 'adaptive', 1.0)
     band_loop('loop_ols_butter_linear', 6, 6000, 20.0, 0.5, 5.0, 5, 'linear', 'butter', 30, 1.0)
     band_loop('loop_lts_butter_octave', 6, 6000, 20.0, 0.25, 4.0, 4, 'octave', 'butter', 30, 0.5, bad=5)
     band_loop('loop_lts_2octave', 6, 6000, 20.0, 0.25, 4.0, 4, '2_octave_over', 'cheby1', 30, 0.75, bad=5)
+    extra()
+

@@ -356,26 +356,27 @@ def test_window_slices_add_up_to_the_full_run():
     np.testing.assert_array_equal(after.vel, full.vel)          # the slice setting does not leak
 
 
-def test_band_sharded_entry_point_under_rccl():
-    """narrow_band_least_squares_parallel() through torch.distributed's nccl (= RCCL) backend: one rank
-    on this box's GPU, sharded code path forced; must equal the serial call bit for bit."""
+@pytest.mark.parametrize('mode', ['all', 'rank'])
+def test_band_sharded_entry_point_under_rccl(mode):
+    """narrow_band_least_squares_parallel() through the library's own RCCL gather (nbls_comm_*; no
+    PyTorch, no launcher): both ways of forming the communicator with this box's one GPU, bands- and
+    windows-sharded paths forced; must equal the serial call bit for bit."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
-           '--master-addr', '127.0.0.1', '--master-port', '29541', os.path.join(root, 'tests', '_dist_gpu_worker.py')]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    cmd = [sys.executable, os.path.join(root, 'tests', '_dist_gpu_worker.py'), mode]
+    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'DIST_GPU_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize('name', ['loop_ols_cheby1_adaptive', 'loop_ols_butter_linear', 'loop_lts_butter_octave',
-                                  'loop_lts_2octave'])
+                                  'loop_lts_2octave', 'loop_lts_101bands'])
 def test_product_against_reference_loop_goldens(name):
     """The GPU path against the fixtures produced by the REFERENCE's own narrow_band_least_squares() /
     ..._parallel() loops (tests/golden/make_goldens.py; ltsva/obspy stubbed by the oracle there): shapes,
-    num_compute_list, zero padding, stdict keys (incl. the overlapping '2_octave_over' bands) and values."""
+    num_compute_list, zero padding, stdict keys (incl. the overlapping '2_octave_over' bands, and the three-
+    character '100_' / '101_' prefixes the reference's zfill(2) gives beyond 99 bands) and values."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'), allow_pickle=False)
     st = synthetic.make_stream(g['data'], float(g['fs']), starttime=17884.0729166667)

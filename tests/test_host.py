@@ -125,11 +125,22 @@ def test_shard_bands_is_a_balanced_partition():
         loads = [sum(costs[b] for b in s) for s in shards]
         assert max(loads) <= 1.2 * (sum(costs) / world)
     assert dist.shard_bands([1.0, 1.0], 4) == [[0], [1], [], []]
-    assert dist.dist_info()[1] == 1
+    assert dist.env_rank()[1] == 1
+
+
+@pytest.mark.parametrize('gold,mode,world', [('loop_ols_butter_linear', 'bands', 3), ('loop_lts_butter_octave', 'bands', 2),
+                                             ('loop_lts_2octave', 'windows', 4), ('loop_ols_cheby1_adaptive', 'bands', 8)])
+def test_sharded_path_one_process_many_devices(gold, mode, world, monkeypatch):
+    """Host logic of narrow_band_least_squares_parallel() in its one-process form (a handle per device,
+    per-device launch threads, gather to root 0) with oracle-backed stand-ins for the device pass."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_worker
+    assert _dist_worker.run_single_process(gold, mode, world, monkeypatch) >= 1
 
 
 @pytest.mark.parametrize('gold,mode', [('loop_ols_butter_linear', 'bands'), ('loop_lts_butter_octave', 'bands'),
-                                       ('loop_ols_butter_linear', 'windows'), ('loop_lts_butter_octave', 'windows')])
+                                       ('loop_ols_butter_linear', 'windows'), ('loop_lts_butter_octave', 'windows'),
+                                       ('loop_lts_butter_octave', 'fail')])
 def test_band_sharded_path_world_size_2_gloo(gold, mode):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -206,3 +217,100 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             m = re.search(r'\.amdhsa_kernel \S*' + k + r'.*?\.amdhsa_private_segment_fixed_size (\d+)', txt, re.S)
             assert m, k
             assert int(m.group(1)) == 0, '%s spills %s bytes per lane' % (k, m.group(1))
+
+
+def test_host_extension_matches_python_equivalents():
+    """csrc/host_ext.cpp (_nbls_host): float repr identical to Python's for every kind of value, the key
+    list and the dictionary identical (keys, order, values, dtype, read-only flag) to the NumPy forms."""
+    from narrow_band_least_squares_amd import engine
+    ext = engine._hostext
+    assert ext is not None, 'narrow_band_least_squares_amd/_nbls_host.so is not built (make -C .../csrc)'
+    import random
+    import struct
+    rng = random.Random(3)
+    vals = [0.0, -0.0, 1.0, 1e16, 1e15, 9999999999999998.0, 1.5e16, 1e-4, 1e-5, 0.00012345, 123456789012345680.0,
+            float('inf'), float('-inf'), 5e-324, 1.7976931348623157e308, 17884.072916666701, 100.0, 1e22, 1e23, 0.1]
+    for _ in range(60000):
+        k = rng.random()
+        if k < 0.3:
+            x = struct.unpack('d', struct.pack('Q', rng.getrandbits(64)))[0]
+        elif k < 0.7:
+            x = 17884.0 + rng.random() * 400
+        else:
+            x = rng.uniform(-1, 1) * 10 ** rng.randint(-20, 20)
+        if x == x:
+            vals.append(x)
+    for x in vals:
+        assert ext.float_repr(x) == repr(x) == str(np.float64(x))
+    assert ext.float_repr(float('nan')) == 'nan'
+    r = np.random.default_rng(4)
+    for P, nch in ((28, 8), (15, 6), (120, 16), (3, 3)):
+        pair_idx = planner.pair_table(nch)
+        B, VL = 5, 37
+        nwin = np.array([37, 30, 0, 36, 1])
+        for frac in (0.0, 0.02, 0.5):
+            w = (r.random((B, VL, P)) >= frac).astype(np.uint8)
+            w[1, 3:20] = 1
+            w[1, 3:20, :2] = 0                      # a run of equal patterns
+            mask = np.packbits(w, axis=-1, bitorder='little')
+            t = 17884.07 + r.random((B, VL))
+            pre = ['%s_' % str(b + 98).zfill(2) for b in range(B)]          # '98_', '99_', '100_', ...
+            keys = ext.time_keys(t, nwin, pre)
+            assert keys == engine._py_time_keys(t, nwin, pre) and len(keys) == nwin.sum()
+            assert ext.time_keys(t, nwin, None) == engine._py_time_keys(t, nwin, None)
+            got = ext.build_stdict(mask, nwin, pair_idx, nch, keys)
+            exp = engine._py_stdict_from_mask(mask, nwin, pair_idx, nch, keys)
+            assert list(got.keys()) == list(exp.keys()) and got['size'] == nch
+            for k in exp:
+                if k != 'size':
+                    np.testing.assert_array_equal(got[k], exp[k])
+                    assert got[k].dtype == exp[k].dtype and not got[k].flags.writeable
+    with pytest.raises(ValueError):
+        ext.build_stdict(np.zeros((1, 2, 4), np.uint8), np.array([2]), planner.pair_table(8), 8, ['a'])
+
+
+def test_one_filter_design_serves_obspy_and_scipy_forms():
+    """planner._design_cached returns ONE SOS for the band-pass obspy applies (corners normalised by
+    fs/2, zpk -> zpk2sos) and the one helpers.py:128 designs for the response plot (fs=Fs): the two are the same
+    floating-point numbers."""
+    from scipy import signal
+    for order in (1, 2, 3, 4, 8):
+        for fs in (20.0, 40.0, 100.0, 37.3):
+            fl = np.logspace(np.log10(0.05), np.log10(fs * 0.49), 25)
+            for i in range(24):
+                z, p, k = signal.iirfilter(order, [fl[i] / (0.5 * fs), fl[i + 1] / (0.5 * fs)], btype='band', ftype='butter',
+                                           output='zpk')
+                a = signal.zpk2sos(z, p, k)
+                b = signal.iirfilter(order, [fl[i], fl[i + 1]], btype='band', ftype='butter', fs=fs, output='sos')
+                np.testing.assert_array_equal(a, b)
+                sa, zp, sr = planner.design_bandpass('butter', fl[i], fl[i + 1], order, 0.01, fs)
+                np.testing.assert_array_equal(sa, a)
+                np.testing.assert_array_equal(sr, b)
+                assert zp is True
+
+
+def test_txtfile_matches_the_references_own_bytes(tmp_path, capsys):
+    """f3: the product's write_txtfile produces byte for byte the file the REFERENCE's
+    write_txtfile wrote for the same grids (tests/golden/txtfile_ref.txt, helpers.py:161-182), and its
+    read_txtfile returns what the reference's read_txtfile returned for that file (txtfile_read.npz,
+    helpers.py:185-235).  Fixtures: tests/golden/make_goldens.py extra."""
+    from narrow_band_least_squares_amd import write_txtfile, read_txtfile
+    gd = os.path.join(ROOT, 'tests', 'golden')
+    g = np.load(os.path.join(gd, 'loop_ols_butter_linear.npz'), allow_pickle=False)
+    d = str(tmp_path) + '/'
+    write_txtfile(d, 'mine', g['vel'], g['baz'], g['mdccm'], g['t'], g['freqlist'], list(g['num_compute']))
+    assert capsys.readouterr().out.split() == [str(n) for n in g['num_compute']]       # the reference prints them
+    ref_bytes = open(os.path.join(gd, 'txtfile_ref.txt'), 'rb').read()
+    assert open(d + 'mine.txt', 'rb').read() == ref_bytes
+    exp = np.load(os.path.join(gd, 'txtfile_read.npz'), allow_pickle=False)
+    open(d + 'ref.txt', 'wb').write(ref_bytes)
+    out = read_txtfile(d, 'ref')
+    names = ('vel', 'baz', 'mdccm', 't', 'freqlist', 'num_compute', 'nbands', 'fmin', 'fmax')
+    ncl = np.asarray(out[5])
+    np.testing.assert_array_equal(ncl, exp['num_compute'])
+    for n, v in zip(names, out):
+        v = np.array(v, dtype=float)
+        if v.ndim == 2:
+            for b in range(v.shape[0]):
+                v[b, ncl[b]:] = 0.0                  # np.empty tails, as in the reference
+        np.testing.assert_array_equal(v, exp[n], err_msg=n)
