@@ -27,6 +27,7 @@ wall time), ``noise`` (the same call on an incoherent-noise trace: the screening
 ``cpu_baseline`` (the CPU oracle timed on this box's host cores: 1 core and all cores) and ``env``.
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -175,11 +176,14 @@ def main():
 
     def one_call(stream, resident=False):
         planner.design_cache_clear()
-        if multi and not shard_traces:
-            return narrow_band_least_squares_parallel(*call_args[:3], stream, *call_args[4:], rij=rij)
-        if call_args is not None and not resident:
-            return narrow_band_least_squares(*call_args[:3], stream, *call_args[4:], rij=rij)
-        return share_call(stream, resident)
+        # the reference's "CAUTION: BT < 5!" prints (narrow_band_least_squares.py:86-87) still happen, but go to
+        # stderr so that stdout carries the one JSON line only
+        with contextlib.redirect_stdout(sys.stderr):
+            if multi and not shard_traces:
+                return narrow_band_least_squares_parallel(*call_args[:3], stream, *call_args[4:], rij=rij)
+            if call_args is not None and not resident:
+                return narrow_band_least_squares(*call_args[:3], stream, *call_args[4:], rij=rij)
+            return share_call(stream, resident)
 
     def share_call(stream, resident):
         """The same whole call for a non-contiguous band share (or with the trace left resident): the body of

@@ -194,6 +194,18 @@ int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t bl
                      void* host_out, int64_t host_bytes);
 int nbls_comm_destroy(nbls_handle* h);
 
+/* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects
+ * between implementations that give IDENTICAL results (A/B timing; tests that check kernels against each other):
+ *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
+ *   "lts_generic_h", "lts_coop_threads", "verify_global", "quantize_slab", "screen_nsl1", "screen_batch_mb",
+ *   "overlap", "filter_nofuse", "filter_nomfma".
+ * A developer build (make dev, -DNBLS_DEVELOPER; nbls_developer_build() == 1) adds "ablate" (skips kernel parts,
+ * results WRONG), "screen_stamps", "lts_stamps", "screen_pad_kb", "lts_pad_kb", "plan_timing"; in the shipped
+ * library those keys return NBLS_ERR_UNSUPPORTED and the corresponding code is not in the kernels.  The library
+ * reads no environment variable. */
+int nbls_set_option(nbls_handle* h, const char* key, int64_t value);
+int nbls_developer_build(void);
+
 /* Enable (1) / disable (0) HIP-event timing of the stages; read the last run's timings. */
 int nbls_set_profiling(nbls_handle* h, int32_t on);
 int nbls_get_timings(nbls_handle* h, nbls_timings* out);
@@ -216,9 +228,8 @@ int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32
 /* Developer statistic of the int8 screening correlator (last unit batch): out4 = {ordered pairs,
  * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
 int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
-/* Developer: mean s_memtime cycles of the screen kernel's phases (needs NBLS_SCREEN_STAMPS=1 at plan time). */
 /* Developer: mean s_memtime cycle counts of the phases of the wave-per-unit FAST-LTS kernel
- * (run with NBLS_SCREEN_STAMPS=1 NBLS_LTS_STAMPS=1): out8 = {setup+medians, elemental starts,
+(developer build, options "screen_stamps" / "lts_stamps"): out8 = {setup+medians, elemental starts,
  * C-steps, candidate peel, refinement, finish, 0, total}. */
 int nbls_debug_lts_stamps(nbls_handle* h, double* out8);
 int nbls_debug_screen_stamps(nbls_handle* h, double* out6);

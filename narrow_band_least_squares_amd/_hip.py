@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libnbls_hip.so')
+# NBLS_LIB: another build of the library (tools/ use the developer build, csrc/libnbls_hip_dev.so)
+LIB_PATH = os.environ.get('NBLS_LIB') or os.path.join(_HERE, 'csrc', 'libnbls_hip.so')
 
 EXPORTS = [
     'nbls_version', 'nbls_device_count', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
@@ -17,7 +18,8 @@ EXPORTS = [
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
-    'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy',
+    'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
+    'nbls_developer_build',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -79,6 +81,7 @@ def load_library(path=None):
     lib.nbls_reserve_results.argtypes = [vp, C.c_int64]
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
+    lib.nbls_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.nbls_set_geometry.argtypes = [vp, dp, ip, dp, C.c_int32]
     plan_args = [vp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip, ip, C.c_int32,
                  C.POINTER(LtsParams), C.c_int32]
@@ -230,6 +233,11 @@ class Handle:
                                      len(tl), _iptr(winlen), _iptr(wininc), int(vector_len), lp,
                                      int(xcorr_impl)))
         self.nbands, self.vector_len = nb, int(vector_len)
+
+    def set_option(self, key, value):
+        """Per-handle implementation switch (``nbls_set_option``; identical results unless the library is the
+        developer build and the key is one of its timing switches)."""
+        self._chk(self.lib.nbls_set_option(self._h, key.encode(), int(value)))
 
     def reserve_results(self, nbytes):
         """Minimum allocation of the result block for the next plans (equal-sized gather blocks)."""

@@ -163,8 +163,6 @@ int nbls_create(int device_id, nbls_handle** out) {
         return fail(nullptr, NBLS_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
     }
     (void)hipStreamCreate(&h->stream2);
-    // two-stream pipeline: measured no gain on MI355X (both kernels fill the chip), off by default
-    { const char* e = getenv("NBLS_OVERLAP"); h->overlap = e ? atoi(e) != 0 : false; }
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     *out = h;
     return NBLS_OK;
@@ -314,8 +312,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     for (int b = 0; b < nbands; ++b) {
         const int W = winlen[b], inc = wininc[b];
         if (W != uniW) uniW = 0;
-        if (W < 2 || inc < 1 || (int64_t)W * 2 * sizeof(double) > 60 * 1024)
-            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2..3840 samples");
+        if (W < 2 || inc < 1 || W > NBLS_MAX_WINDOW)
+            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2.." + std::to_string(NBLS_MAX_WINDOW) +
+                        " samples (two windows of the general correlator must fit a CU's 160 KB of LDS)");
         // len(arange(0, npts - W, inc))
         const int64_t span = h->npts - W;
         int64_t n = span > 0 ? (span + inc - 1) / inc : 0;
@@ -409,7 +408,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         size_t lds_;
         const bool ok = h->d_xij && nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
         if (xcorr_impl == 3 && !ok)
-            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..16 channels and a window that fits LDS");
+            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..33 channels and channel images that fit a CU's LDS");
         if (xcorr_impl == 0 && ok) xcorr_impl = 3;
         h->xcorr_impl = xcorr_impl;
     }
@@ -418,21 +417,19 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         size_t lds_;
         (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
         // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
-        int64_t batch_mb = 96;
-        { const char* be = getenv("NBLS_SCREEN_BATCH_MB"); if (be && atoi(be) > 0) batch_mb = atoi(be); }   // developer
+        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 96;
         int64_t batch = (int64_t)(batch_mb << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
         if (batch > U) batch = U > 0 ? U : 1;
         h->screen_batch = batch;
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
         if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (10 + WP_ / 32) * sizeof(double)))) return rc;
-        if (getenv("NBLS_SCREEN_STAMPS")) {
+        if (h->opt.screen_stamps || h->opt.lts_stamps) {
             if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * 8 * sizeof(unsigned long long)))) return rc;
         }
         if ((rc = ensure(h, &h->d_cand, &h->cap_cand, (size_t)batch * h->nchans * h->nchans * 32 * sizeof(int32_t)))) return rc;
     }
     h->lts = lts != nullptr;
-    { const char* e = getenv("NBLS_LTS_IMPL"); h->lts_impl = e ? atoi(e) : 0; }
     if (lts) {
         h->ltsp = *lts;
         h->ltsp.starts = nullptr;
@@ -447,7 +444,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if ((rc = alloc_copy(h, &h->d_xs, xs.data(), xs.size()))) return rc;
     }
     h->planned = true;
-    if (getenv("NBLS_PLAN_TIMING")) {
+    if (h->opt.plan_timing) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "nbls_plan: tables %.3f ms, uploads %.3f ms, buffers+rest %.3f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
@@ -474,7 +471,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     h->solve_done = false;
-    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && h->overlap;
+    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && h->opt.overlap;
     if (stage_mask & 2) HIPCHK(h, nbls_launch_xcorr(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if ((stage_mask & 4) && !h->solve_done) HIPCHK(h, nbls_launch_solve(h));
@@ -572,6 +569,47 @@ int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(out, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, h->stream));   // ordered after the pass
     return finish_pass(h);
+}
+
+int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
+    if (!h || !key) return NBLS_ERR_ARG;
+    struct Key { const char* name; int nbls_options::*field; bool developer; };
+    static const Key keys[] = {
+        {"lts_impl", &nbls_options::lts_impl, false},
+        {"lts_generic_h", &nbls_options::lts_generic_h, false},
+        {"lts_coop_threads", &nbls_options::lts_coop_threads, false},
+        {"verify_global", &nbls_options::verify_global, false},
+        {"quantize_slab", &nbls_options::quantize_slab, false},
+        {"screen_nsl1", &nbls_options::screen_nsl1, false},
+        {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
+        {"overlap", &nbls_options::overlap, false},
+        {"filter_nofuse", &nbls_options::filter_nofuse, false},
+        {"filter_nomfma", &nbls_options::filter_nomfma, false},
+        {"ablate", &nbls_options::ablate, true},
+        {"screen_stamps", &nbls_options::screen_stamps, true},
+        {"lts_stamps", &nbls_options::lts_stamps, true},
+        {"screen_pad_kb", &nbls_options::screen_pad_kb, true},
+        {"lts_pad_kb", &nbls_options::lts_pad_kb, true},
+        {"plan_timing", &nbls_options::plan_timing, true},
+    };
+    for (const Key& k : keys) {
+        if (strcmp(k.name, key) != 0) continue;
+#ifndef NBLS_DEVELOPER
+        if (k.developer) return fail(h, NBLS_ERR_UNSUPPORTED, std::string("option '") + key + "' exists only in the developer build (make dev)");
+#endif
+        h->opt.*(k.field) = (int)value;
+        h->planned = false;                 // options are read by nbls_plan and by the launchers of the next pass
+        return NBLS_OK;
+    }
+    return fail(h, NBLS_ERR_ARG, std::string("unknown option '") + key + "'");
+}
+
+int nbls_developer_build(void) {
+#ifdef NBLS_DEVELOPER
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int nbls_set_profiling(nbls_handle* h, int32_t on) {

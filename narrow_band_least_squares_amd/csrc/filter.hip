@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
 template <int S>
 hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
     constexpr int D = 2 * S;
-    static const bool no_mfma = getenv("NBLS_FILTER_NOMFMA") != nullptr;   // developer: VALU state kernel
+    const bool no_mfma = h->opt.filter_nomfma != 0;                        // option: VALU state kernel
     if (!states_ready && !a.reverse && (16 % D) == 0 && a.in_mod == a.nchans && !no_mfma) {
         const int nbands = a.nseries / a.nchans;
         const int rows = (nbands * D + 15) / 16;
@@ -422,7 +422,7 @@ hipError_t run_filter(nbls_handle* h) {
     a.final_pass = h->zero_phase ? 0 : 1;
     // zero-phase: the forward apply also accumulates the chunk states of the backward pass (it has
     // every output sample in hand), which saves the backward pass's read of the whole buffer
-    const bool fuse = h->zero_phase && !getenv("NBLS_FILTER_NOFUSE");
+    const bool fuse = h->zero_phase && !h->opt.filter_nofuse;
     a.cstate_next = fuse ? h->d_cstate2 : nullptr;
     hipError_t e = run_pass<S>(h, a, false);
     if (e != hipSuccess || !h->zero_phase) return e;

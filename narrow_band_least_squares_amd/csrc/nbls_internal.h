@@ -12,17 +12,42 @@
 #define NBLS_FILTER_TILE 32        // samples per LDS tile row
 #define NBLS_FILTER_GROUP 64       // chunks per carry group
 #define NBLS_MAX_PAIRS 512
+#define NBLS_MAX_WINDOW 10000     // samples: 2 * W * 8 B of LDS in xcorr_simple_kernel (<= 160 KB)
 #define NBLS_MAX_STARTS 1024
 #define NBLS_MAX_CAND 16
 
+// Per-handle switches (nbls_set_option).  The first group selects between implementations that give
+// IDENTICAL results (A/B timing, tests that compare kernels with each other).  The second group exists only
+// in a -DNBLS_DEVELOPER build (`make dev`): in-kernel time stamps and ablation switches that make results
+// WRONG on purpose; the shipped library has none of that code in its kernels.
+struct nbls_options {
+    int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 3 generic only where no register kernel exists
+    int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
+    int lts_coop_threads = 0;  // > 0: workgroup size of the cooperative LTS kernel
+    int verify_global = 0;     // 1: verify candidates from global memory instead of LDS
+    int quantize_slab = 0;     // 1: the LDS-slab quantize kernel for every window length
+    int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
+    int screen_batch_mb = 96;  // quantised-window bytes per unit batch
+    int overlap = 0;           // 1: solve of batch k on a second stream while batch k+1 is correlated
+    int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
+    int filter_nomfma = 0;     // 1: VALU state kernel
+    // ---- developer build only ----
+    int ablate = 0;            // skip parts of the screening / verify kernels (timing; results wrong)
+    int screen_stamps = 0;     // s_memtime phase stamps of the screening kernel
+    int lts_stamps = 0;        // ... of the wave-per-unit LTS kernel
+    int screen_pad_kb = 0;     // extra LDS per screening workgroup (occupancy experiment)
+    int lts_pad_kb = 0;        // extra LDS per LTS workgroup
+    int plan_timing = 0;       // print the host phases of nbls_plan
+};
+
 struct nbls_handle {
     int device = 0;
+    nbls_options opt;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
     std::vector<hipEvent_t> pev;    // pipeline hand-off events
     bool fuse_solve = false;        // set by nbls_execute_stages when correlation + solve run pipelined
     bool solve_done = false;
-    bool overlap = true;            // NBLS_OVERLAP=0 disables the two-stream pipeline (profiling)
     std::string err;
 
     // ---- trace (HBM resident) ----
@@ -106,7 +131,6 @@ struct nbls_handle {
 
     // ---- LTS ----
     bool lts = false;
-    int lts_impl = 0;              // 0 auto, 1 generic kernel, 3 generic kernel only for pair counts without a register kernel (NBLS_LTS_IMPL env, for A/B tests)
     nbls_lts_params ltsp{};
     int32_t* d_starts = nullptr;   // [S][4]
     double* d_rew = nullptr;       // [P+1]

@@ -754,7 +754,12 @@ __global__ __launch_bounds__(256, 2) void solve_lts_wave_kernel(SArgs a, int nun
     const int64_t o = (int64_t)band * a.vector_len + w;
 
     const int wave_id = blockIdx.x * 4 + wv;
+#ifdef NBLS_DEVELOPER      // phase stamps exist in the developer build only
     unsigned long long* stp = (a.stamps && lane == 0 && wave_id < a.stamp_waves) ? a.stamps + (size_t)wave_id * 8 : nullptr;
+#else
+    unsigned long long* const stp = nullptr;
+    (void)wave_id;
+#endif
     if (stp) stp[0] = __builtin_amdgcn_s_memtime();
     double* base = sm + (size_t)wv * slab_doubles;
     double* tauv = base;
@@ -1126,7 +1131,7 @@ int lts_wave_slab_doubles(int P, int S) {
 template <int PT, int H>
 hipError_t launch_fast_h(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
     int slab = lts_wave_slab_doubles(PT, a.nstarts);
-    { const char* e = getenv("NBLS_LTS_PAD_KB"); if (e) slab += atoi(e) * 128; }   // occupancy experiment
+    slab += h->opt.lts_pad_kb * 128;                                              // developer: occupancy experiment
     const size_t shm = (size_t)slab * 4 * sizeof(double);
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)solve_lts_wave_kernel<PT, H>,
@@ -1141,7 +1146,7 @@ hipError_t launch_fast_h(nbls_handle* h, const SArgs& a, int nunits, hipStream_t
 // selection network pruned to that output; every other h runs the generic one.
 template <int PT, int HALF>
 hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t st) {
-    static const bool generic_only = getenv("NBLS_LTS_GENERIC_H") != nullptr;   // developer
+    const bool generic_only = h->opt.lts_generic_h != 0;
     if (a.h == HALF && !generic_only) return launch_fast_h<PT, HALF>(h, a, nunits, st);
     return launch_fast_h<PT, 0>(h, a, nunits, st);
 }
@@ -1725,15 +1730,14 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.stamps = nullptr;
     a.stamp_waves = 0;
     {
-        const char* e = getenv("NBLS_LTS_STAMPS");
-        if (e && atoi(e) && h->d_stamps) {
+        if (h->opt.lts_stamps && h->d_stamps) {
             a.stamps = h->d_stamps;
             const int64_t cap = (int64_t)(h->cap_stamps / (8 * sizeof(unsigned long long)));
             a.stamp_waves = (int)(nunits < cap ? nunits : cap);
             h->lts_stamp_waves = a.stamp_waves;
         }
     }
-    if (h->lts_impl != 1) {
+    if (h->opt.lts_impl != 1) {
         switch (h->npairs) {     // register-resident kernel for 4..8 elements (larger P spills registers)
             case 6: return launch_fast<6, 4>(h, a, nunits, st);
             case 10: return launch_fast<10, 6>(h, a, nunits, st);
@@ -1743,7 +1747,7 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
             default: break;
         }
     }
-    if (h->lts_impl != 1 && h->lts_impl != 3) {
+    if (h->opt.lts_impl != 1 && h->opt.lts_impl != 3) {
         // wave-cooperative kernel for every other pair count (9..32 elements)
         const size_t cshm = lts_coop_lds_bytes(h->npairs, a.nstarts);
         if (cshm <= 160 * 1024 && h->npairs <= 512) {
@@ -1751,7 +1755,7 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
             if (ce != hipSuccess) return ce;
             int threads = a.nstarts > 256 ? 512 : 256;
             if (cshm > 80 * 1024 && a.nstarts > 512 - 64) threads = 1024;    // one workgroup per CU anyway: give it all four wave slots per SIMD
-            { const char* te = getenv("NBLS_LTS_COOP_THREADS"); if (te && atoi(te) >= 64) threads = atoi(te); }   // developer
+            if (h->opt.lts_coop_threads >= 64) threads = h->opt.lts_coop_threads;
             hipLaunchKernelGGL(solve_lts_coop_kernel, dim3(nunits), dim3(threads), cshm, st, a, nunits);
             return hipGetLastError();
         }

@@ -53,4 +53,35 @@ __device__ inline unsigned int max_u32(unsigned int v) {
     return max(max(a, b), max(c, d));
 }
 
+// NumPy's answer for one pair when a window holds NaN or Inf samples (sum of squares not finite), by ONE
+// wave (lanes stride the samples; xa, xb in LDS or global memory).  The reference computes
+//     cij = np.correlate(a, b, 'full') / sqrt(sum a^2 * sum b^2);  argmax(cij);  cij.max()
+// and np.argmax / max treat NaN as the maximum (first NaN wins):
+//   * a NaN sample in either window makes the norm NaN -> every lag NaN -> index 0;
+//   * else an Inf sample makes the norm Inf: lags whose overlap touches it are Inf/Inf = NaN, the others
+//     finite/Inf = 0 -> the first lag that touches an Inf: sample m of `a` is touched by np.correlate
+//     indices m .. m+W-1, sample m of `b` by W-1-m .. 2W-2-m -> min(first Inf of a, W-1 - last Inf of b);
+//   * the maximum itself is NaN either way.
+// (Sums that overflow to Inf without an Inf sample — |x| > 1e150 — fall back to index 0.)
+__device__ inline int nonfinite_argmax(const double* xa, const double* xb, int W, int lane) {
+    int has_nan = 0, first_a = 0x7fffffff, last_b = -1;
+    for (int n = lane; n < W; n += 64) {
+        const double va = xa[n], vb = xb[n];
+        has_nan |= (va != va) || (vb != vb);
+        if (fabs(va) == __builtin_inf() && n < first_a) first_a = n;
+        if (fabs(vb) == __builtin_inf()) last_b = n;            // ascending n: the last one stays
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        has_nan |= __shfl_xor(has_nan, off, 64);
+        first_a = min(first_a, __shfl_xor(first_a, off, 64));
+        last_b = max(last_b, __shfl_xor(last_b, off, 64));
+    }
+    if (has_nan) return 0;
+    int k = 0x7fffffff;
+    if (first_a != 0x7fffffff) k = first_a;
+    if (last_b >= 0 && W - 1 - last_b < k) k = W - 1 - last_b;
+    return k == 0x7fffffff ? 0 : k;
+}
+__device__ inline bool finite_f64(double v) { return fabs(v) < __builtin_inf(); }   // false for NaN and +-Inf
+
 }  // namespace nbls_wave

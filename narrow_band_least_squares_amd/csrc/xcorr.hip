@@ -13,6 +13,7 @@
 // and it is FP64-throughput bound (2*P*W^2 flop per unit against ~8*N*inc bytes), not
 // HBM bound.
 #include "nbls_internal.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -109,12 +110,18 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
     }
     if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_k[tid >> 6] = bestk; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {
         for (int i = 1; i < 4; ++i)
             if (better(red_v[i], red_k[i], best, bestk)) { best = red_v[i]; bestk = red_k[i]; }
-        const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + k;
-        a.lag[o] = (W - 1) - bestk;
-        a.cmax[o] = best / sqrt(ssa * ssb);
+        if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {      // NaN / Inf samples: NumPy's semantics
+            bestk = nbls_wave::nonfinite_argmax(sa, sb, W, tid);
+            best = __builtin_nan("");
+        }
+        if (tid == 0) {
+            const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + k;
+            a.lag[o] = (W - 1) - bestk;
+            a.cmax[o] = best / sqrt(ssa * ssb);
+        }
     }
 }
 
@@ -230,6 +237,24 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
             const int c2 = ci + (N - 1) * ss;           // wave cj, partner ci
             if (better(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
         }
+        if (!nbls_wave::finite_f64(nrm[ci]) || !nbls_wave::finite_f64(nrm[cj])) {
+            // NaN / Inf samples: NumPy's semantics (see wave_ops.h nonfinite_argmax), scanned by this one thread
+            const double* xa = sm + (size_t)ci * CS + PF;
+            const double* xb = sm + (size_t)cj * CS + PF;
+            bool has_nan = false;
+            int first_a = 0x7fffffff, last_b = -1;
+            for (int n = 0; n < W; ++n) {
+                const double va = xa[n], vb = xb[n];
+                has_nan = has_nan || (va != va) || (vb != vb);
+                if (fabs(va) == __builtin_inf() && n < first_a) first_a = n;
+                if (fabs(vb) == __builtin_inf()) last_b = n;
+            }
+            int kk = 0x7fffffff;
+            if (first_a != 0x7fffffff) kk = first_a;
+            if (last_b >= 0 && W - 1 - last_b < kk) kk = W - 1 - last_b;
+            bk = (has_nan || kk == 0x7fffffff) ? 0 : kk;
+            bv = __builtin_nan("");
+        }
         const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + tid;
         a.lag[o] = (W - 1) - bk;
         a.cmax[o] = bv / sqrt(nrm[ci] * nrm[cj]);
@@ -290,6 +315,10 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     }
     const int64_t nblocks = h->nunits * h->npairs;
     const size_t shm = (size_t)2 * h->maxW * sizeof(double);
+    if (shm > 48 * 1024) {      // long windows (W up to 10000): opt in to more than the default dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void*)xcorr_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
     h->xcorr_impl_used = 1;
     hipLaunchKernelGGL(xcorr_simple_kernel, dim3((unsigned)nblocks), dim3(256), shm, h->stream, a);
     return hipGetLastError();

@@ -89,7 +89,7 @@ __device__ inline int qpad(int n) { return n + (n >> 3); }
 __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     extern __shared__ double qsm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wv;
+    const int item = blockIdx.x * (blockDim.x >> 6) + wv;      // 1..4 waves per workgroup (what the slabs leave room for)
     const int N = a.nchans;
     if (item >= a.nu * N) return;
     const int ul = item / N, ch = item % N;
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
         long long eg = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int q = (int)rint(sm[g * 9 + e] * scale);
+            double xq = sm[g * 9 + e] * scale;
+            xq = (xq == xq) ? xq : 0.0;          // NaN sample, or Inf * 0: quantised as 0 (verify applies NumPy's rule)
+            int q = (int)rint(xq);
             q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
             const int lo = ((q + 64) & 127) - 64;
             const int hi = (q - lo) >> 7;
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
             long long eg = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                int q = (int)rint(x[i][e] * scale);
+                double xq = x[i][e] * scale;
+                xq = (xq == xq) ? xq : 0.0;      // NaN sample, or Inf * 0: quantised as 0 (verify applies NumPy's rule)
+                int q = (int)rint(xq);
                 q = q > QMAX ? QMAX : (q < -QMAX ? -QMAX : q);
                 const int lo = ((q + 64) & 127) - 64;
                 const int hi = (q - lo) >> 7;
@@ -325,9 +329,16 @@ __device__ inline float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x
     MFMA_I8(AH, bl, CM)
 #define TILE_L(AL, CM) MFMA_I8(AL, bh, CM)
 
+// Developer build only (-DNBLS_DEVELOPER): phase stamps and ablation switches; compiled out of the shipped kernels.
+#ifdef NBLS_DEVELOPER
 __device__ inline void stamp(unsigned long long* p, int slot) {
     if (p) { p[slot] = __builtin_amdgcn_s_memtime(); }
 }
+#define NBLS_ABL(bits) (a.ablate & (bits))
+#else
+__device__ inline void stamp(unsigned long long*, int) {}
+#define NBLS_ABL(bits) 0
+#endif
 
 constexpr int TB = 4;            // tile steps processed together (they share the B fragments)
 
@@ -362,7 +373,11 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int cp = (rem >> 3) % NCP;
     const int pg = (rem >> 3) / NCP;
     if (ul >= a.nu) return;
+#ifdef NBLS_DEVELOPER
     unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#else
+    unsigned long long* const stp = nullptr;
+#endif
     stamp(stp, 0);
     const int half = wv >> 2;                        // which sliding channel of the pair
     const int ci = NSL * cp + half;
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int rowA = wv & (nrowA - 1), subA = wv >> (NSL == 2 ? 2 : 1);
     const int hsA = rowA >> 1, limbA = rowA & 1;
     const int chsA = NSL * cp + hsA;
-    const bool stage_on = !(a.ablate & 2);
+    const bool stage_on = !(NBLS_ABL(2));
     const int8_t* srcA = a.qbuf + (((int64_t)ul * N + (chsA < N ? chsA : 0)) * 2 + limbA) * WP;
     unsigned char* dstA = Acop + ((size_t)(hsA * 2 + limbA) * 8) * CSA;
     // first pass of the sliding rows (128 groups = 1024 samples per row pass)
@@ -576,7 +591,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
 // 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
 #define SCREEN_EPILOGUE(NT, ACC)                                                                          \
-    if (colvalid && !(a.ablate & 4)) {                                                                    \
+    if (colvalid && !(NBLS_ABL(4))) {                                                                    \
         float v[NT * 4];                                                                                  \
         float gmx = -__builtin_inff();                                                                    \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                  \
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
         if (p >= ngrp4) continue;
         const int D0 = TB * p * step;
-        if (rnd > 0 && !(a.ablate & 32)) {
+        if (rnd > 0 && !(NBLS_ABL(32))) {
             bool prunable = true;
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const int klen = W - D0;
         const unsigned char* qa_h = pAh + D0;
         const unsigned char* qa_l = pAl + D0;
-        if (!(a.ablate & 1)) {
+        if (!(NBLS_ABL(1))) {
         // the partner fragments of the NEXT K step are fetched while this step's products run
         v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
         if (step == 32) {
@@ -811,7 +826,11 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
                                    double ssa, double ssb, int lane, double* best_out, int* bestk_out) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
-    if (ssa == 0.0 || ssb == 0.0) {          // dead channel: every lag is 0, np.argmax gives index 0
+    if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {
+        // NaN / Inf samples in a window (gappy trace): the screening saw them as zeros; the answer is NumPy's
+        bestk = nbls_wave::nonfinite_argmax(xa, xb, W, lane);
+        best = __builtin_nan("");
+    } else if (ssa == 0.0 || ssb == 0.0) {   // dead channel: every lag is 0, np.argmax gives index 0
         best = 0.0;
         bestk = 0;
     } else {
@@ -890,7 +909,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
             ssB[q] = a.qmeta[((int64_t)ul * N + cj) * a.qms];
         }
     }
-    for (int ch = wv; ch < N && !(a.ablate & 128); ch += nwv) {
+    for (int ch = wv; ch < N && !(NBLS_ABL(128)); ch += nwv) {
         const double* src = a.filt + ((int64_t)band * N + ch) * a.npts_pad + t0;
         double* dst = vsm + (size_t)ch * W;
         if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
@@ -904,7 +923,7 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     }
     if (tid == 0) vsm[(size_t)N * W] = 0.0;              // the zero slot of wave_dot
     __syncthreads();
-    for (int k0 = (a.ablate & 64) ? P : 0; k0 * nwv + wv < P; k0 += 4) {
+    for (int k0 = (NBLS_ABL(64)) ? P : 0; k0 * nwv + wv < P; k0 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = wv + (k0 + q) * nwv;
@@ -1038,7 +1057,7 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     // the caller when they still fit (nbls_screen_tables)
     const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 64;
     const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 64;
-    static const bool force1 = getenv("NBLS_SCREEN_NSL1") != nullptr;    // developer: one sliding channel per workgroup
+    const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
     if (lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
     return *lds <= 160 * 1024 && *lds >= 1024;
@@ -1076,8 +1095,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.vector_len = h->vector_len;
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
-    { const char* e = getenv("NBLS_ABLATE"); a.ablate = e ? atoi(e) : 0; }
-    a.stamps = h->d_stamps;
+    a.ablate = h->opt.ablate;
+    a.stamps = h->opt.screen_stamps ? h->d_stamps : nullptr;
     {
         // solved once per array size (cached); a failed/over-budget search falls back to the linear
         // skew o[jj] = jj, which is correct and at most 2-way conflicted
@@ -1093,11 +1112,11 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         }
         for (int q = 0; q < 32; ++q) a.boff[q] = (int8_t)cache_o[q];
     }
-    { const char* pe = getenv("NBLS_SCREEN_PAD_KB"); if (pe) lds += (size_t)atoi(pe) * 1024; }   // developer: occupancy experiment
+    lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t vlds = ((size_t)N * h->maxW + 2) * sizeof(double);   // + the zero slot
-    { const char* e = getenv("NBLS_VERIFY_GLOBAL"); if (e && atoi(e)) vlds = 1u << 30; }   // timing experiment
+    if (h->opt.verify_global) vlds = 1u << 30;
     if (vlds <= 80 * 1024) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
         if (e != hipSuccess) return e;
@@ -1120,13 +1139,23 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         {
             const int gpl = (a.WP / 8 + 63) / 64;          // 8-sample groups per lane
             const size_t qlds = (size_t)4 * (a.WP / 8 + 8) * sizeof(double);
-            static const bool slab = getenv("NBLS_QUANTIZE_SLAB") != nullptr;   // developer: the LDS-slab form
+            const bool slab = h->opt.quantize_slab != 0;                        // option: the LDS-slab form
             if (gpl <= 4 && !slab)
                 hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
             else if (gpl <= 8 && !slab)
                 hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
-            else
-                hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + 3) / 4), dim3(256), (size_t)4 * (a.WP + a.WP / 4 + 8) * sizeof(double), h->stream, a);
+            else {
+                // one LDS slab per wave: as many waves per workgroup (<= 4) as fit a CU's 160 KB
+                const size_t slab = (size_t)(a.WP + a.WP / 4 + 8) * sizeof(double);
+                int nwq = (int)((160 * 1024) / slab);
+                nwq = nwq > 4 ? 4 : nwq;
+                if (nwq < 1) return hipErrorInvalidValue;
+                if (slab * nwq > 48 * 1024) {
+                    hipError_t qe = hipFuncSetAttribute((const void*)quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slab * nwq));
+                    if (qe != hipSuccess) return qe;
+                }
+                hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + nwq - 1) / nwq), dim3(64 * nwq), slab * nwq, h->stream, a);
+            }
         }
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;

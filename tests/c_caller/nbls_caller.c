@@ -1,0 +1,88 @@
+/* A plain C caller of libnbls_hip.so, compiled against include/nbls.h only (no Python, no ctypes):
+ * what a non-Python host binds.  Reads a problem from a flat binary file written by
+ * tests/test_c_caller.py, runs it through nbls_run() — plan + execute + sync + fetch in one call — and
+ * writes the outputs next to it.
+ *
+ * File layout (little endian):  int32 nchans, npairs, nbands, nsections, zero_phase, taper_len,
+ * vector_len, lts_flag;  int64 npts;  double fs;  then double trace[nchans][npts], xij[npairs][2],
+ * int32 pair_idx[npairs][2], double xpinv[2][npairs], sos[nbands][nsections][6], taper_left[taper_len],
+ * taper_right[taper_len], int32 winlen[nbands], wininc[nbands];  if lts_flag: double alpha, int32 h, nstarts,
+ * csteps, csteps2, ncand, int32 starts[nstarts][4], double xij_mad[2], raw_factor, rew_table[npairs+1],
+ * quantile, zero_scale.
+ * Output: double vel, baz, mdccm, sigma_tau [nbands][vector_len], int32 nwin[nbands],
+ * int32 lag[nbands][vector_len][npairs], uint8 weights[nbands][vector_len][npairs]. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "nbls.h"
+
+static void rd(void* p, size_t n, FILE* f) {
+    if (n && fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { fprintf(stderr, "usage: %s problem.bin result.bin\n", argv[0]); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    int32_t hd[8];
+    int64_t npts;
+    double fs;
+    rd(hd, sizeof hd, f); rd(&npts, 8, f); rd(&fs, 8, f);
+    const int nchans = hd[0], P = hd[1], B = hd[2], S = hd[3], zero_phase = hd[4], tl_n = hd[5], VL = hd[6], lts_flag = hd[7];
+    double* trace = malloc((size_t)nchans * npts * 8);
+    double* xij = malloc((size_t)P * 2 * 8);
+    int32_t* pair = malloc((size_t)P * 2 * 4);
+    double* xpinv = malloc((size_t)P * 2 * 8);
+    double* sos = malloc((size_t)B * (S ? S : 1) * 6 * 8);
+    double* tl = malloc((size_t)(tl_n ? tl_n : 1) * 8);
+    double* tr = malloc((size_t)(tl_n ? tl_n : 1) * 8);
+    int32_t* winlen = malloc((size_t)B * 4);
+    int32_t* wininc = malloc((size_t)B * 4);
+    rd(trace, (size_t)nchans * npts * 8, f); rd(xij, (size_t)P * 16, f); rd(pair, (size_t)P * 8, f); rd(xpinv, (size_t)P * 16, f);
+    rd(sos, (size_t)B * S * 48, f); rd(tl, (size_t)tl_n * 8, f); rd(tr, (size_t)tl_n * 8, f);
+    rd(winlen, (size_t)B * 4, f); rd(wininc, (size_t)B * 4, f);
+    nbls_lts_params lp;
+    int32_t* starts = NULL;
+    double* rew = NULL;
+    if (lts_flag) {
+        int32_t iv[5];
+        rd(&lp.alpha, 8, f); rd(iv, sizeof iv, f);
+        lp.h = iv[0]; lp.nstarts = iv[1]; lp.csteps = iv[2]; lp.csteps2 = iv[3]; lp.ncand = iv[4];
+        starts = malloc((size_t)lp.nstarts * 16);
+        rew = malloc((size_t)(P + 1) * 8);
+        rd(starts, (size_t)lp.nstarts * 16, f); rd(lp.xij_mad, 16, f); rd(&lp.raw_factor, 8, f);
+        rd(rew, (size_t)(P + 1) * 8, f); rd(&lp.quantile, 8, f); rd(&lp.zero_scale, 8, f);
+        lp.starts = starts;
+        lp.rew_table = rew;
+    }
+    fclose(f);
+
+    nbls_handle* h = NULL;
+    int rc = nbls_create(0, &h);
+    if (rc) { fprintf(stderr, "nbls_create: %d %s\n", rc, nbls_last_error(NULL)); return 1; }
+    if ((rc = nbls_set_trace(h, trace, nchans, npts, fs)) || (rc = nbls_set_geometry(h, xij, pair, xpinv, P))) {
+        fprintf(stderr, "setup: %d %s\n", rc, nbls_last_error(h));
+        return 1;
+    }
+    const size_t cells = (size_t)B * VL;
+    double* grids = calloc(4 * cells, 8);
+    int32_t* nwin = calloc(B, 4);
+    int32_t* lag = calloc(cells * P, 4);
+    uint8_t* wts = calloc(cells * P, 1);
+    rc = nbls_run(h, B, S ? sos : NULL, S, zero_phase, tl, tr, tl_n, winlen, wininc, VL, lts_flag ? &lp : NULL, 0,
+                  grids, grids + cells, grids + 2 * cells, grids + 3 * cells, nwin, lag, NULL, wts, NULL);
+    if (rc) { fprintf(stderr, "nbls_run: %d %s\n", rc, nbls_last_error(h)); return 1; }
+    /* error path of the ABI: a vector_len that is too small must be refused with NBLS_ERR_ARG, not crash */
+    if (nwin[0] > 1) {
+        const int bad = nbls_plan(h, B, S ? sos : NULL, S, zero_phase, tl, tr, tl_n, winlen, wininc, 1, NULL, 0);
+        if (bad != NBLS_ERR_ARG) { fprintf(stderr, "expected NBLS_ERR_ARG, got %d\n", bad); return 1; }
+    }
+    nbls_destroy(h);
+    f = fopen(argv[2], "wb");
+    if (!f) { perror(argv[2]); return 2; }
+    fwrite(grids, 8, 4 * cells, f); fwrite(nwin, 4, B, f); fwrite(lag, 4, cells * P, f); fwrite(wts, 1, cells * P, f);
+    fclose(f);
+    printf("C_CALLER_OK version %d units %d\n", nbls_version(), (int)nwin[0]);
+    return 0;
+}

@@ -1,0 +1,195 @@
+"""GPU parity tests at the unit SHAPES of every BASELINE.json configuration, through the whole drop-in call
+(narrow_band_least_squares -> C ABI) against the CPU oracle: cfg-2 at its own alpha with all 24 bands, cfg-4
+(16 elements, 100 Hz, W = 3000, alpha 0.5, 500 LCG starts), cfg-5 (32 elements, 128 bands: three-character
+'100_' key prefixes).  Trace lengths are cut so that the oracle finishes in seconds; the arithmetic per unit is
+the configuration's.  Tolerances as in test_gpu_parity.py: lags / weights / stdict exact, vel / baz 1e-9."""
+import numpy as np
+import pytest
+
+from narrow_band_least_squares_amd import engine, narrow_band_least_squares, narrow_band_loop, synthetic
+from narrow_band_least_squares_amd.narrow_band_least_squares import _band_prefix
+
+from test_gpu_parity import _compare_nbls, _compare_ltsva, _cfg, _ostream, RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub_config(c, bands):
+    """The configuration restricted to a contiguous band range (same trace, same windows)."""
+    d = dict(c)
+    d['NBANDS'] = len(bands)
+    d['freqlist'] = list(c['freqlist'][bands[0]:bands[-1] + 2])
+    d['WINLEN_list'] = list(c['WINLEN_list'][bands[0]:bands[-1] + 1])
+    return d
+
+
+def _rows_vs_oracle(oracle, c, got, bands):
+    """Rows and stdict entries of selected bands of a whole call against filter_data + ltsva of the oracle."""
+    for b in bands:
+        stf, _, _ = oracle.filter_data(_ostream(oracle, c), c['ftype'], c['freqlist'][b], c['freqlist'][b + 1], c['order'],
+                                       c['ripple'])
+        out = oracle.ltsva(stf, None, None, c['WINLEN_list'][b], c['overlap'], c['alpha'], rij=c['rij'])
+        n = len(out[0])
+        assert got[6][b] == n
+        np.testing.assert_allclose(got[0][b, :n], out[0], rtol=RTOL, err_msg='vel band %d' % b)
+        np.testing.assert_allclose(got[1][b, :n], out[1], rtol=RTOL, err_msg='baz band %d' % b)
+        np.testing.assert_allclose(got[2][b, :n], out[3], rtol=RTOL, err_msg='mdccm band %d' % b)
+        np.testing.assert_array_equal(got[3][b, :n], out[2])
+        assert not got[0][b, n:].any() and not got[3][b, n:].any()
+        pre = _band_prefix(b + 1)
+        mine = {k: v for k, v in got[4].items() if k.startswith(pre) and k != 'size'}
+        theirs = {pre + k: v for k, v in out[4].items() if k != 'size'}
+        assert mine.keys() == theirs.keys(), 'stdict keys of band %d' % b
+        for k in theirs:
+            np.testing.assert_array_equal(mine[k], theirs[k])
+
+
+def test_cfg2_all_bands_at_its_own_alpha(oracle):
+    """cfg-2: 6 elements, 24 log bands 0.1-5 Hz, alpha = 0.75 (h = 12, all 105 two-subsets), 20 Hz, 30 s windows."""
+    c = _cfg('cfg2', 0.2)
+    assert c['alpha'] == 0.75 and c['NBANDS'] == 24
+    got, exp = _compare_nbls(oracle, c, np.logspace(-2, 1, 64))
+    assert sum(got[6]) == 24 * 46 and any(k != 'size' for k in got[4])
+
+
+def test_cfg4_unit_shape_through_the_whole_call(oracle):
+    """cfg-4's unit: 16 elements (P = 120, h = 61), 100 Hz, W = 3000 samples, alpha = 0.5, 500 LCG-random starts —
+    3 bands x 21 windows through narrow_band_least_squares() against the oracle; lags and weights of one band
+    exactly; the int8 screening correlator and the cooperative LTS kernel are the ones that run."""
+    c = _cfg('cfg4', 345.0 / 86400.0)
+    assert c['N'] == 16 and c['fs'] == 100.0 and c['alpha'] == 0.5
+    sub = _sub_config(c, [50, 51, 52])
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        got, exp = _compare_nbls(oracle, sub, np.logspace(-2, np.log10(50.0), 64))
+        assert h.timings()['xcorr_impl'] == 3
+    finally:
+        h.set_profiling(False)
+    assert got[6] == [21, 21, 21]
+    from narrow_band_least_squares_amd import planner
+    lp = planner.lts_plan(planner.co_array(c['rij'])[0], 0.5)
+    assert lp['h'] == 61 and lp['starts'].shape[0] == 500
+    # lags and weights of the middle band, exactly
+    stf, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', c['freqlist'][51], c['freqlist'][52], 2, 0.01)
+    _compare_ltsva(oracle, c, stf, 30.0, 0.5)
+    # the mistimed element shows up in the dropped-element dictionary
+    dropped = np.concatenate([v for k, v in got[4].items() if k != 'size'])
+    assert np.bincount(dropped, minlength=17).argmax() == 16
+
+
+def test_cfg5_more_than_99_bands(oracle):
+    """cfg-5: 32 elements (P = 496, h = 249, 500 LCG starts), 128 bands in ONE call: bands 100..128 get the
+    three-character key prefix the reference's str(band).zfill(2) produces ('100_', narrow_band_least_squares.py:120).
+    Selected bands (first, 99th, 100th, 101st, last) against the oracle; every band's keys carry its own prefix."""
+    c = _cfg('cfg5', 75.0 / 3600.0)
+    assert c['N'] == 32 and c['NBANDS'] == 128
+    fr = np.logspace(-2, 1, 16)
+    w = np.zeros(16)
+    got = narrow_band_least_squares(c['WINLEN_list'], c['overlap'], c['alpha'], c['st'], None, None, 128, w, w,
+                                    c['freqlist'], c['band_type'], fr, c['ftype'], c['order'], c['ripple'], rij=c['rij'])
+    assert got[6] == [3] * 128 and got[0].shape[0] == 128
+    _rows_vs_oracle(oracle, c, got, [0, 98, 99, 100, 127])
+    keys = [k for k in got[4] if k != 'size']
+    assert any(k.startswith('100_') for k in keys) and any(k.startswith('128_') for k in keys)
+    assert all(k.split('_')[0] == str(int(k.split('_')[0])).zfill(2) for k in keys)
+    assert got[4]['size'] == 32
+
+
+def test_narrow_band_loop_lts_branch(oracle):
+    """narrow_band_loop() under LTS (reference narrow_band_least_squares.py:204-214): the dictionary of one
+    band comes back flattened into two object arrays (times, elements) — the joblib transport form."""
+    c = _cfg('cfg2', 0.2)
+    fr = np.logspace(-2, 1, 32)
+    vl = 60
+    row = narrow_band_loop(7, c['freqlist'], c['band_type'], fr, c['st'], 'butter', 2, 0.01, None, None, c['WINLEN_list'], 0.5,
+                           0.75, vl, rij=c['rij'])
+    stf, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', c['freqlist'][7], c['freqlist'][8], 2, 0.01)
+    out = oracle.ltsva(stf, None, None, c['WINLEN_list'][7], 0.5, 0.75, rij=c['rij'])
+    n = len(out[0])
+    assert int(row[7]) == n and len(row[0]) == vl
+    np.testing.assert_allclose(row[0][:n], out[0], rtol=RTOL)
+    np.testing.assert_allclose(row[1][:n], out[1], rtol=RTOL)
+    np.testing.assert_array_equal(row[3][:n], out[2])
+    times, elements = row[4], row[5]
+    assert times.dtype == object and elements.dtype == object and len(times) == len(out[4])
+    exp_items = list(out[4].items())
+    assert list(times) == [k for k, _ in exp_items]
+    for (k, v), e in zip(exp_items, elements):
+        if k == 'size':
+            assert e == 6
+        else:
+            np.testing.assert_array_equal(e, v)
+
+
+def _hostile_stream(oracle, kind):
+    """A pre-filtered 6-element (kind 'long': 4-element) stream that stresses the screening correlator."""
+    rng = np.random.default_rng(11)
+    fs, nchans, winlen = 20.0, 6, 30.0
+    if kind == 'long':
+        fs, nchans, winlen = 200.0, 4, 25.0                    # W = 5000 samples: the LDS-slab quantiser
+    rij = synthetic.array_geometry(nchans, 1.0, seed=40 + nchans)
+    npts = int(5.2 * winlen * fs)
+    t = np.arange(npts) / fs
+    if kind == 'noise':                                         # no common signal at all
+        data = rng.standard_normal((nchans, npts))
+    elif kind == 'sinusoid':                                    # periodic: every period is a near-tie
+        delays = rng.uniform(0, 0.3, nchans)
+        data = np.array([np.sin(2 * np.pi * 0.537 * (t - d)) for d in delays])
+    else:
+        data = synthetic.plane_wave(rij, npts, fs, 0.5, 0.4 * fs if kind != 'long' else 8.0, seed=5)
+    W = int(winlen * fs)
+    if kind == 'spike':                                         # one sample 1e6 x the signal in every window
+        data[2, W // 3::W // 2] = 1e6
+    elif kind == 'dc':
+        data[4] += 250.0
+    elif kind == 'ties':                                        # a constant against an alternating +-1 channel:
+        data[0] = 1.0                                           # their correlation is exactly 0 or +-1 at every
+        data[1] = (-1.0) ** np.arange(npts)                     # lag — hundreds of exactly tied maxima
+    elif kind == 'nan':
+        data[1, W + 17] = np.nan                                # windows 1 and 2 of channel 1
+        data[3, 3 * W // 2 + 5] = np.nan
+    elif kind == 'inf':
+        data[1, W + 17] = np.inf
+        data[5, W + 400] = -np.inf
+        data[0, 3 * W + 3] = np.inf                             # last windows: one channel only
+    c = dict(fs=fs, rij=rij - rij.mean(axis=1, keepdims=True))
+    return c, oracle.make_stream(data, fs, starttime=17884.0729166667), winlen
+
+
+@pytest.mark.parametrize('kind', ['noise', 'sinusoid', 'spike', 'dc', 'ties', 'long', 'nan', 'inf'])
+@pytest.mark.parametrize('alpha', [1.0, 0.5])
+def test_hostile_inputs_keep_exact_lags(oracle, kind, alpha):
+    """Inputs that break the assumptions the int8 screening is tuned for — incoherent noise, a pure sinusoid
+    (periodic near-ties), a 1e6 x spike per window (the 15-bit quantisation of everything else collapses to 0),
+    a DC offset, exactly tied maxima (candidate overflow -> full-lag fallback), W > 4096 (slab quantiser) — and NaN / Inf samples, where the answer is NumPy's (first NaN lag
+    wins, wave_ops.h nonfinite_argmax): lags, maxima, weights exactly the oracle's in every case."""
+    c, st, winlen = _hostile_stream(oracle, kind)
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        _compare_ltsva(oracle, c, st, winlen, alpha)
+        assert h.timings()['xcorr_impl'] == 3                   # the screening correlator ran, not a fallback kernel
+        stats = h.screen_stats()
+    finally:
+        h.set_profiling(False)
+    assert stats['pairs'] > 0
+    if kind == 'ties':
+        # hundreds of lags tie for the maximum: the candidate lists of that pair overflow, so these windows really
+        # went through the interval / full-lag FP64 fallback (and np.argmax's first-index rule decided)
+        assert stats['overflow'] > 0, stats
+
+
+def test_raw_trace_with_a_gap_propagates_like_sosfilt(oracle):
+    """A NaN in the RAW trace: the IIR band-pass spreads it over the rest of that channel (forward pass) and,
+    zero-phase, over all of it; every pair of that element then follows the NaN rule.  Same dropped pairs and
+    same rows as the oracle (scipy.sosfilt + NumPy)."""
+    c = _cfg('cfg1', 0.25)
+    data = np.array(c['data'])
+    data[2, 1234] = np.nan
+    st = synthetic.make_stream(data, c['fs'], starttime=c['st'][0].stats.starttime)
+    d = dict(c)
+    d['st'], d['data'] = st, data
+    sub = _sub_config(d, [2, 3])
+    got, exp = _compare_nbls(oracle, sub, np.logspace(-2, 1, 16))
+    assert np.isfinite(got[0][:, :got[6][0]]).all()            # the other five elements still give a solution

@@ -200,7 +200,7 @@ def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha, nine):
 @pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5), (20, 0.75), (32, 0.5)])
 def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alpha):
     """9..16 elements (36..120 pairs, 500 random starts): the wave-cooperative LTS kernel against the
-    oracle, and against the generic lane-per-start kernel (NBLS_LTS_IMPL=1) bit for bit."""
+    oracle, and against the generic lane-per-start kernel (option "lts_impl" = 1) bit for bit."""
     fs, npts = 20.0, 3000
     rij = synthetic.array_geometry(nchans, 1.5)
     data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=nchans - 1, seed=11)
@@ -212,8 +212,12 @@ def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alph
     t0 = oracle.start_datenum(stf_o[0].stats.starttime)
     kw = dict(prefiltered=True, want_z=True)
     a = engine.process(filt, fs, t0, c['rij'], [(None, None)], [30.0], 0.5, alpha, **kw)
-    monkeypatch.setenv('NBLS_LTS_IMPL', '1')
-    b = engine.process(filt, fs, t0, c['rij'], [(None, None)], [30.0], 0.5, alpha, **kw)
+    h = engine.get_handle()
+    h.set_option('lts_impl', 1)
+    try:
+        b = engine.process(filt, fs, t0, c['rij'], [(None, None)], [30.0], 0.5, alpha, **kw)
+    finally:
+        h.set_option('lts_impl', 0)
     np.testing.assert_array_equal(a.z, b.z)
     np.testing.assert_array_equal(a.weights, b.weights)
     np.testing.assert_array_equal(a.sigma_tau, b.sigma_tau)
@@ -293,8 +297,26 @@ def test_kernel_variants_agree(monkeypatch):
     np.testing.assert_allclose(r_mfma.cmax, r_valu.cmax, rtol=1e-12, atol=1e-15)
     for k in ('vel', 'baz', 'sigma_tau', 'weights', 'z'):
         np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_valu, k))
-    monkeypatch.setenv('NBLS_LTS_IMPL', '1')
-    r_gen = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
+    h = engine.get_handle()
+    h.set_option('lts_impl', 1)
+    try:
+        r_gen = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
+        # the other identical-result switches of the library, all at once
+        for key in ('verify_global', 'quantize_slab', 'screen_nsl1', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
+            h.set_option(key, 1)
+        h.set_option('lts_impl', 0)
+        r_alt = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=3, **kw)
+    finally:
+        for key in ('lts_impl', 'verify_global', 'quantize_slab', 'screen_nsl1', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
+            h.set_option(key, 0)
+    np.testing.assert_array_equal(r_alt.lag, r_mfma.lag)
+    for k in ('vel', 'baz', 'weights'):
+        np.testing.assert_array_equal(getattr(r_alt, k), getattr(r_mfma, k))
+    if not h.lib.nbls_developer_build():          # timing switches that falsify results are not in the shipped library
+        with pytest.raises(ValueError):
+            h.set_option('ablate', 1)
+    with pytest.raises(ValueError):
+        h.set_option('no_such_option', 1)
     for k in ('vel', 'baz', 'sigma_tau', 'weights', 'z', 'mdccm'):
         np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_gen, k))
 

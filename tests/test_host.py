@@ -314,3 +314,111 @@ def test_txtfile_matches_the_references_own_bytes(tmp_path, capsys):
             for b in range(v.shape[0]):
                 v[b, ncl[b]:] = 0.0                  # np.empty tails, as in the reference
         np.testing.assert_array_equal(v, exp[n], err_msg=n)
+
+
+# ---- checks of the recalled FAST-LTS / geodesy pieces that do NOT share text with the oracle --------------
+# (tests/test_host.py::test_lts_plan_matches_oracle_constants compares planner.py with its restatement in the
+#  oracle; the tests below pin the same functions to hand-worked numbers, closed forms and published constants.)
+
+def test_lts_subset_size_table():
+    """h = 2*floor((P+p+1)/2) - P + 2*(P - floor((P+p+1)/2))*alpha, p = 2 (robustbase h.alpha.n): worked by hand."""
+    table = {(15, 0.75): 12, (28, 0.5): 15, (120, 0.5): 61, (496, 0.5): 249, (6, 0.5): 4, (10, 0.5): 6, (21, 0.5): 12,
+             (15, 0.5): 9, (28, 0.75): 21, (28, 0.9): 25, (120, 0.75): 90, (36, 0.5): 19}
+    for (P, alpha), h in table.items():
+        assert planner.lts_h(P, alpha) == h, (P, alpha)
+    for P in range(3, 600):
+        assert planner.lts_h(P, 0.5) == (P + 3) // 2           # the smallest subset that still has a majority
+        assert planner.lts_h(P, 0.999999) in (P - 1, P)
+        hs = [planner.lts_h(P, a) for a in np.linspace(0.5, 0.99, 25)]
+        assert all(b >= a for a, b in zip(hs, hs[1:]))          # monotone in alpha
+
+
+def test_lcg_subsets_by_closed_form():
+    """robustbase's uniran: seed <- (seed*5761 + 999) mod 65536 from seed 0.  First seeds worked by hand, the
+    whole sequence against the closed form seed_n = 999*(5761^n - 1)/5760 mod 65536 (big integers, no loop), full
+    period (Hull-Dobell: c odd, a-1 divisible by 4), and the subsets rebuilt from that sequence."""
+    def seed(n):
+        return (999 * (5761 ** n - 1) // 5760) % 65536
+    assert [seed(n) for n in (1, 2, 3, 4)] == [999, 54606, 13365, 57500]
+    assert len({seed(n) for n in range(1, 4097)}) == 4096
+    assert seed(65536) == 0 and seed(32768) != 0                 # period exactly 65536
+    for P in (120, 496, 36):
+        subs = planner.uniran_subsets(P)
+        assert subs.shape == (500, 2)
+        n, rebuilt = 0, []
+        for _ in range(500):
+            pick = []
+            while len(pick) < 2:
+                n += 1
+                idx = int(seed(n) / 65536.0 * P)
+                if idx not in pick:
+                    pick.append(idx)
+            rebuilt.append(pick)
+        assert subs.tolist() == rebuilt
+    assert planner.uniran_subsets(120)[:2].tolist() == [[1, 99], [24, 105]]        # by hand from the four seeds above
+
+
+def test_consistency_factor_by_numerical_integration():
+    """The raw / reweighted consistency factor is 1/sqrt(E[x^2 | |x| <= q]) of a standard normal truncated to the
+    central m/n of its mass — checked by quadrature, plus its limits."""
+    from scipy import integrate
+    from scipy.stats import norm
+    for m, n in ((15, 28), (61, 120), (249, 496), (12, 15), (27, 28), (3, 28)):
+        q = norm.ppf(0.5 * (1 + m / n))
+        second, _ = integrate.quad(lambda x: x * x * norm.pdf(x), -q, q, epsabs=1e-13, epsrel=1e-13)
+        expect = 1.0 / np.sqrt(second / (m / n))
+        assert abs(planner._consfactor(m, n) - expect) < 1e-10 * expect
+        assert planner._consfactor(m, n) > 1.0
+    assert planner._consfactor(28, 28) == 1.0
+    tab = planner._consfactor_table(200)
+    assert np.all(np.diff(tab) < 0) and abs(tab[-1] - planner._consfactor(199, 200)) == 0.0     # -> 1 as m -> n
+    assert tab[-1] < 1.15 and tab[0] > 50
+
+
+def test_small_sample_correction_closed_form():
+    """LTScnp2-style finite-sample factor: fp(n) = 1 - exp(k0)/n^k1 with (k0, k1) fitted through the tabulated
+    points n = 3p^2 and 5p^2, interpolated in alpha between 0.5 and 0.875 and on to 1 at alpha = 1.  Evaluated here
+    through the explicit two-point solution instead of the linear solve."""
+    import math
+    p = 2
+
+    def fp(c, n):
+        y0 = math.log(-c[0][0] / p ** c[1][0])
+        y1 = math.log(-c[0][1] / p ** c[1][1])
+        k1 = (y0 - y1) / math.log(c[2][1] / c[2][0])
+        k0 = y0 + k1 * math.log(c[2][0] * p * p)
+        return 1.0 - math.exp(k0) / n ** k1
+    for n in (15, 28, 120, 496):
+        for alpha in (0.5, 0.6, 0.75, 0.875, 0.9, 0.99):
+            for c500, c875 in ((planner._RAW_500, planner._RAW_875), (planner._REW_500, planner._REW_875)):
+                f5, f8 = fp(c500, n), fp(c875, n)
+                f = f5 + (f8 - f5) / 0.375 * (alpha - 0.5) if alpha <= 0.875 else f8 + (1 - f8) / 0.125 * (alpha - 0.875)
+                got = planner._cnp2(p, n, alpha, c500, c875)
+                assert abs(got - 1.0 / f) < 1e-12 * abs(got)
+    # the correction shrinks with the sample size and vanishes at alpha = 1
+    assert planner._cnp2(2, 28, 0.5, planner._RAW_500, planner._RAW_875) > planner._cnp2(2, 496, 0.5, planner._RAW_500, planner._RAW_875) > 1.0
+    assert abs(planner._cnp2(2, 28, 1.0, planner._RAW_500, planner._RAW_875) - 1.0) < 1e-12
+    lp = planner.lts_plan(planner.co_array(np.random.default_rng(2).standard_normal((2, 8)))[0], 0.5)
+    assert abs(lp['quantile'] - 2.241402727604947) < 1e-12       # qnorm(0.9875)
+
+
+def test_vincenty_against_published_constants():
+    """WGS84 quarter meridian 10 001 965.729 m and one degree of equatorial longitude a*pi/180 (published values),
+    reciprocity of the azimuths, and agreement with the spherical law of cosines on a short line."""
+    from narrow_band_least_squares_amd.helpers import vincenty_inverse
+    d, az, _ = vincenty_inverse(0.0, 10.0, 90.0, 10.0)
+    assert abs(d - 10001965.729) < 2e-3 and abs(az) < 1e-9
+    d, az, baz = vincenty_inverse(0.0, 0.0, 0.0, 1.0)
+    assert abs(d - 6378137.0 * np.pi / 180) < 1e-6 and abs(az - 90.0) < 1e-9 and abs(baz - 270.0) < 1e-9
+    d12, a12, b12 = vincenty_inverse(64.87, -147.86, 64.875, -147.85)
+    d21, a21, b21 = vincenty_inverse(64.875, -147.85, 64.87, -147.86)
+    assert abs(d12 - d21) < 1e-6 and abs(a12 - b21) < 1e-7 and abs(b12 - a21) < 1e-7
+    # sphere of the local radius of curvature: agrees to 1e-4 relative over ~700 m
+    lat = np.radians(64.8725)
+    a_, f_ = 6378137.0, 1 / 298.257223563
+    e2 = f_ * (2 - f_)
+    M = a_ * (1 - e2) / (1 - e2 * np.sin(lat) ** 2) ** 1.5
+    Nn = a_ / np.sqrt(1 - e2 * np.sin(lat) ** 2)
+    dy = np.radians(0.005) * M
+    dx = np.radians(0.01) * Nn * np.cos(lat)
+    assert abs(d12 - np.hypot(dx, dy)) < 1e-4 * d12
