@@ -9,8 +9,9 @@ H2D/D2H and the final gather"): upload of the raw trace from the stream's own bu
 plan on the host, the device pass (filter + taper, pairwise cross-correlation / lag pick, MdCCM, FAST-LTS +
 reweighting for every (band, window) unit), ONE D2H copy of the result block (grids + packed LTS weights),
 the filter responses, and the reference's dropped-element dictionary ``stdict`` with one entry per window.
-``value`` = units / that wall time.  Beside it: ``kernel_only_ms`` (the device pass alone, HIP events on the
-library's stream), ``value_trace_resident`` (same call without the upload), and ``stage_ms``.  The filter-design
+``value`` = units / that wall time.  Beside it: ``kernel_only_ms`` (the device pass alone — all bands as one pass,
+executed back to back, HIP events on the library's stream), ``value_trace_resident`` (same call without the
+upload), and ``stage_ms``.  The filter-design
 cache of the host planner is cleared before every step, so no step reuses host work of an earlier one.
 
 N = 1: the configuration named by --config (default cfg-3 = BASELINE.json's 8-element metric config; cfg-4 is
@@ -172,7 +173,6 @@ def main():
     edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in bands]
 
     h = engine.get_handle(local_rank if multi else None)
-    h.set_profiling(True)
 
     def one_call(stream, resident=False):
         planner.design_cache_clear()
@@ -181,45 +181,71 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):
             if multi and not shard_traces:
                 return narrow_band_least_squares_parallel(*call_args[:3], stream, *call_args[4:], rij=rij)
-            if call_args is not None and not resident:
+            if call_args is not None:
                 return narrow_band_least_squares(*call_args[:3], stream, *call_args[4:], rij=rij)
             return share_call(stream, resident)
 
     def share_call(stream, resident):
-        """The same whole call for a non-contiguous band share (or with the trace left resident): the body of
-        narrow_band_least_squares() with explicit band edges."""
+        """The same whole call for a non-contiguous band share: the body of narrow_band_least_squares() with
+        explicit band edges (a share of the bands cannot be expressed through ``freqlist``)."""
         from narrow_band_least_squares_amd.narrow_band_least_squares import _band_prefix, _vector_len
         from scipy import signal
         rows, fs_, t0 = engine.stream_rows(stream)
         vl = _vector_len(winlens, c['overlap'], stream)
         w_rows = np.zeros((nb, len(fr)), dtype=complex)
         h_rows = np.zeros((nb, len(fr)), dtype=complex)
+        lts_ = c['alpha'] < 1.0
 
         def host_side(res):
             for n_, s_ in enumerate(res.sos):
                 w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_)
-            if c['alpha'] < 1.0:
+            if lts_:
                 res.keys = engine.time_keys(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
+                res.stdict = {}
+
+        def group_done(res, b0, b1):
+            if lts_:
+                engine.stdict_from_mask(res.mask[b0:b1], res.nwin[b0:b1], res.pair_idx, res.nchans, res.keys,
+                                        into=res.stdict, k0=int(np.sum(res.nwin[:b0])))
         res = engine.process(rows, fs_, t0, rij, edges, winlens, c['overlap'], c['alpha'], c['ftype'], c['order'],
-                             c['ripple'], vector_len=vl, host_overlap=host_side, upload=not resident, handle=h)
-        sd = None if c['alpha'] == 1.0 else engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
-        return (res.vel, res.baz, res.mdccm, res.t, sd, res.sigma_tau, [int(x) for x in res.nwin], w_rows, h_rows)
+                             c['ripple'], vector_len=vl, host_overlap=host_side, group_done=group_done)
+        return (res.vel, res.baz, res.mdccm, res.t, res.stdict if lts_ else None, res.sigma_tau, [int(x) for x in res.nwin],
+                w_rows, h_rows)
 
     def barrier():
         h.sync()
         if multi:
             td.barrier()
 
-    def timed(stream, steps, resident=False):
+    def measure_kernels(stream, steps):
+        """The device pass alone: all bands of this rank as ONE pass, planned once, executed back to back with
+        HIP-event timing of the stages on the library's stream (what r01's bench reported as its step)."""
+        rows, fs_, t0_ = engine.stream_rows(stream)
+        my = list(range(nb))
+        if multi and not shard_traces:
+            npairs_ = nchans * (nchans - 1) // 2
+            my = dist.shard_bands(dist.band_costs(npts, fs_, winlens, c['overlap'], npairs_), world)[rank]
+        prep = engine.prepare(nchans, npts, fs_, rij, [edges[b] for b in my], [winlens[b] for b in my], c['overlap'],
+                              c['alpha'], c['ftype'], c['order'], c['ripple'])
+        h.set_profiling(True)
+        engine.launch(h, rows, prep)
+        h.sync()
         kern, stages = [], []
+        for _ in range(steps):
+            h.execute()
+            h.sync()
+            tm = h.timings()
+            kern.append(tm['total_ms'])
+            stages.append(tm)
+        h.set_profiling(False)
+        return kern, stages
+
+    def timed(stream, steps, resident=False):
         barrier()
         t0 = time.perf_counter()
         out = None
         for _ in range(steps):
             out = one_call(stream, resident)
-            tm = h.timings()
-            kern.append(tm['total_ms'])
-            stages.append(tm)
         barrier()
         el = time.perf_counter() - t0
         if multi:
@@ -227,11 +253,12 @@ def main():
             tt = torch.tensor([el], dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             el = float(tt.item())
-        return el, kern, stages, out
+        return el, out
 
     for _ in range(args.warmup):
         one_call(st)
-    elapsed, kern, stages, out = timed(st, args.steps)
+    elapsed, out = timed(st, args.steps)
+    kern, stages = measure_kernels(st, max(3, args.steps // 2))
     nwin_list = out[6]
     units_call = int(sum(nwin_list))
     total_units = units_call * (world if shard_traces else 1)
@@ -304,16 +331,22 @@ def main():
                              'note': 'SURVEY 8(d): algorithmic bytes (8*N*inc + 40 + ceil(P/8) per unit) / wall time of the whole call'},
             'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('NBLS_')},
         }
-    # the same call with the trace already resident in HBM (no upload) ...
-    el_r, kern_r, _, _ = timed(st, max(2, args.steps // 2), resident=True) if not (multi and not shard_traces) else (None, None, None, None)
-    if rank == 0 and el_r is not None:
-        line['value_trace_resident'] = total_units * max(2, args.steps // 2) / el_r
+    # what the upload of the trace costs inside a call (host-blocking copy from the stream's buffers)
+    rows_up = engine.stream_rows(st)[0]
+    t_up = time.perf_counter()
+    for _ in range(3):
+        h.set_trace_rows(rows_up, fs)
+    upload_ms = (time.perf_counter() - t_up) / 3 * 1e3
+    if rank == 0:
+        line['upload_ms'] = upload_ms
+        line['value_trace_resident'] = total_units / ((ms_step - upload_ms) * 1e-3)     # derived: the call minus the upload
     # ... and on incoherent noise of the same shape (no common signal: nothing for the pruning to exploit)
     if not args.no_noise and not multi:
         rng = np.random.default_rng(7)
         noise = synthetic.make_stream(rng.standard_normal((nchans, npts)), fs)
         one_call(noise)
-        el_n, kern_n, stages_n, _ = timed(noise, max(2, args.steps // 2))
+        el_n, _ = timed(noise, max(2, args.steps // 2))
+        kern_n, stages_n = measure_kernels(noise, 3)
         line['noise'] = {'value': units_call * max(2, args.steps // 2) / el_n, 'ms_per_step': el_n / max(2, args.steps // 2) * 1e3,
                          'kernel_only_ms': float(np.mean(kern_n)),
                          'xcorr_screen_ms': float(np.mean([s['screen_ms'] for s in stages_n])),

@@ -97,6 +97,10 @@ int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t 
  * Stream are separate arrays, this form uploads them without first packing them into one host block. */
 int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts, double fs);
 
+/* Same trace as another handle of the SAME device, copied device-to-device (no second trip over PCIe): the
+ * band groups of one call run as concurrent passes on several handles of one GPU. */
+int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src);
+
 /* Co-array: xij[npairs][2] (km; pair k = (i,j), i<j, lexicographic; xij = r_i - r_j),
  * pair_idx[npairs][2], xpinv[2][npairs] = pseudo-inverse of xij (OLS). */
 int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx,

@@ -19,7 +19,7 @@ EXPORTS = [
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
-    'nbls_developer_build',
+    'nbls_developer_build', 'nbls_set_trace_from',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -81,6 +81,7 @@ def load_library(path=None):
     lib.nbls_reserve_results.argtypes = [vp, C.c_int64]
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
+    lib.nbls_set_trace_from.argtypes = [vp, vp]
     lib.nbls_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.nbls_set_geometry.argtypes = [vp, dp, ip, dp, C.c_int32]
     plan_args = [vp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip, ip, C.c_int32,
@@ -183,6 +184,11 @@ class Handle:
         ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
         self._chk(self.lib.nbls_set_trace_rows(self._h, ptrs, len(keep), npts, float(fs)))
         self.nchans, self.npts, self.fs = len(keep), npts, float(fs)
+
+    def set_trace_from(self, other):
+        """The trace of another handle on the same GPU, copied device-to-device."""
+        self._chk(self.lib.nbls_set_trace_from(self._h, other._h))
+        self.nchans, self.npts, self.fs = other.nchans, other.npts, other.fs
 
     def set_geometry(self, xij, pair_idx, xpinv):
         xij = _f64(xij)

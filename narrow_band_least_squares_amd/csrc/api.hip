@@ -27,6 +27,15 @@ int fail(nbls_handle* h, int code, const std::string& msg) {
                         std::string(#call) + ": " + hipGetErrorString(e_));                    \
     } while (0)
 
+// Blocking copy ON THE HANDLE'S STREAM.  The streams are non-blocking (hipStreamNonBlocking) and nothing in
+// the library touches the NULL stream: a plain hipMemcpy would wait for every other handle of the process
+// that is busy on this GPU (the band groups of a pipelined call run on several handles at once).
+hipError_t copy_sync(nbls_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream);
+}
+
 template <typename T>
 int ensure(nbls_handle* h, T** p, size_t* cap, size_t need_bytes) {
     if (*p && *cap >= need_bytes) return 0;
@@ -53,7 +62,9 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
         HIPCHK(h, hipMalloc((void**)p, need));
         cap = need;
     }
-    if (n) HIPCHK(h, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    // queued on the handle's stream; nbls_plan / nbls_set_geometry wait for the stream before they return
+    // (StreamGuard), i.e. before the host buffers go away
+    if (n) HIPCHK(h, hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -61,6 +72,14 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
 // double: one step is s' = A s + g x.  Returns, for a chunk of C samples and carry groups of G chunks,
 //   fw[t][d]    = (A^(C-1-t) g)[d]         zero-state end state  e = sum_t fw[t] x_t
 //   mpow[j]     = (A^C)^j, j = 0..G        chunk / group transitions
+// Waits for the handle's stream when the enclosing API call returns, on every exit path: host tables that
+// alloc_copy queued must have been read by then.
+struct StreamGuard {
+    nbls_handle* h;
+    explicit StreamGuard(nbls_handle* hh) : h(hh) {}
+    ~StreamGuard() { (void)hipStreamSynchronize(h->stream); }
+};
+
 void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
     constexpr int DM = 2 * NBLS_MAX_SECTIONS;
     const int D = 2 * S;
@@ -158,11 +177,11 @@ int nbls_create(int device_id, nbls_handle** out) {
         return fail(nullptr, NBLS_ERR_ARG, "nbls_create: device_id out of range");
     nbls_handle* h = new nbls_handle();
     h->device = device_id;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete h;
         return fail(nullptr, NBLS_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
     }
-    (void)hipStreamCreate(&h->stream2);
+    (void)hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     *out = h;
     return NBLS_OK;
@@ -227,6 +246,33 @@ int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t 
     return set_trace_impl(h, nullptr, trace, nchans, npts, fs);
 }
 
+int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src) {
+    if (!h || !src) return NBLS_ERR_ARG;
+    if (!src->d_trace) return fail(h, NBLS_ERR_STATE, "nbls_set_trace_from: the source handle has no trace");
+    if (h == src) return NBLS_OK;
+    if (h->device != src->device) return fail(h, NBLS_ERR_ARG, "nbls_set_trace_from: handles are on different devices");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t need = (size_t)src->nchans * src->npts_pad * sizeof(double);
+    if (!h->d_trace || h->cap_trace < need) {
+        if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; h->cap_trace = 0; }
+        HIPCHK(h, hipMalloc((void**)&h->d_trace, need));
+        h->cap_trace = need;
+    }
+    // the source's upload has completed (nbls_set_trace* return after it); ordered on THIS handle's stream
+    HIPCHK(h, hipMemcpyAsync(h->d_trace, src->d_trace, need, hipMemcpyDeviceToDevice, h->stream));
+    if (h->nchans != src->nchans && h->d_xij) {
+        (void)hipFree(h->d_xij); h->d_xij = nullptr;
+        h->caps.erase((const void*)&h->d_xij);
+        h->npairs = 0;
+    }
+    h->nchans = src->nchans;
+    h->npts = src->npts;
+    h->npts_pad = src->npts_pad;
+    h->fs = src->fs;
+    h->planned = false;
+    return NBLS_OK;
+}
+
 int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts, double fs) {
     if (!h) return NBLS_ERR_ARG;
     if (!rows || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace_rows: bad argument");
@@ -248,6 +294,7 @@ int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx
     if (!(det > 1e-12 * (sxx + syy) * (sxx + syy)))
         return fail(h, NBLS_ERR_GEOMETRY, "co-array is rank deficient (collinear array)");
     HIPCHK(h, hipSetDevice(h->device));
+    StreamGuard guard(h);
     int rc;
     if ((rc = alloc_copy(h, &h->d_xij, xij, (size_t)npairs * 2))) return rc;
     if ((rc = alloc_copy(h, &h->d_pair, pair_idx, (size_t)npairs * 2))) return rc;
@@ -301,6 +348,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
             if (lts->starts[i] >= P) return fail(h, NBLS_ERR_ARG, "nbls_plan: start index out of range");
     }
     HIPCHK(h, hipSetDevice(h->device));
+    StreamGuard guard(h);
 
     h->W.assign(winlen, winlen + nbands);
     h->inc.assign(wininc, wininc + nbands);
@@ -519,16 +567,16 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
     const double* dg[4] = {h->d_vel, h->d_baz, h->d_mdccm, h->d_sig};
     double* hg[4] = {vel, baz, mdccm, sigma_tau};
     if (vel && baz == vel + cells && mdccm == baz + cells && sigma_tau == mdccm + cells) {
-        HIPCHK(h, hipMemcpy(vel, h->d_vel, 4 * cells * sizeof(double), hipMemcpyDeviceToHost));   // caller's grids are one block too
+        HIPCHK(h, copy_sync(h, vel, h->d_vel, 4 * cells * sizeof(double), hipMemcpyDeviceToHost));   // caller's grids are one block too
     } else {
         for (int g = 0; g < 4; ++g)
-            if (hg[g]) HIPCHK(h, hipMemcpy(hg[g], dg[g], cells * sizeof(double), hipMemcpyDeviceToHost));
+            if (hg[g]) HIPCHK(h, copy_sync(h, hg[g], dg[g], cells * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (nwin) memcpy(nwin, h->nwin.data(), h->nbands * sizeof(int32_t));
-    if (lag) HIPCHK(h, hipMemcpy(lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (cmax) HIPCHK(h, hipMemcpy(cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost));
-    if (weights) HIPCHK(h, hipMemcpy(weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost));
-    if (z) HIPCHK(h, hipMemcpy(z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost));
+    if (lag) HIPCHK(h, copy_sync(h, lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cmax) HIPCHK(h, copy_sync(h, cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost));
+    if (weights) HIPCHK(h, copy_sync(h, weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost));
+    if (z) HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost));
     return NBLS_OK;
 }
 
@@ -538,9 +586,10 @@ int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out) {
     if (band < 0 || band >= h->nbands) return fail(h, NBLS_ERR_ARG, "nbls_fetch_filtered: band out of range");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy2D(out, h->npts * sizeof(double),
-                          h->d_filt + (size_t)band * h->nchans * h->npts_pad, h->npts_pad * sizeof(double),
-                          h->npts * sizeof(double), h->nchans, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy2DAsync(out, h->npts * sizeof(double),
+                               h->d_filt + (size_t)band * h->nchans * h->npts_pad, h->npts_pad * sizeof(double),
+                               h->npts * sizeof(double), h->nchans, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return NBLS_OK;
 }
 
@@ -581,6 +630,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"verify_global", &nbls_options::verify_global, false},
         {"quantize_slab", &nbls_options::quantize_slab, false},
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
+        {"screen_static", &nbls_options::screen_static, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
@@ -644,11 +694,11 @@ int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double
     HIPCHK(h, hipMalloc((void**)&da, 64 * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&db, 64 * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&dout, 256 * sizeof(double)));
-    HIPCHK(h, hipMemcpy(da, a, 64 * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(db, b, 64 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_sync(h, da, a, 64 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_sync(h, db, b, 64 * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, nbls_launch_probe_mfma(h, da, db, dout));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, dout, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, out, dout, 256 * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return NBLS_OK;
 }
@@ -663,7 +713,7 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
     const int N = h->nchans;
     const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
     std::vector<int32_t> c((size_t)last * N * N * 32);
-    HIPCHK(h, hipMemcpy(c.data(), h->d_cand, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, c.data(), h->d_cand, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     for (int64_t u = 0; u < last; ++u)
         for (int i = 0; i < N; ++i)
@@ -688,7 +738,7 @@ int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
     const int64_t nwg = ((last + 7) / 8) * 8 * h->nchans;   // upper bound (one or two channels per workgroup)
     std::vector<unsigned long long> st((size_t)nwg * 8);
-    HIPCHK(h, hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) out6[i] = 0.0;
     int64_t cnt = 0;
     for (int64_t g = 0; g < nwg; ++g) {
@@ -708,7 +758,7 @@ int nbls_debug_lts_stamps(nbls_handle* h, double* out8) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<unsigned long long> st((size_t)h->lts_stamp_waves * 8);
-    HIPCHK(h, hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = 0.0;
     int64_t cnt = 0;
     for (int64_t g = 0; g < h->lts_stamp_waves; ++g) {
@@ -730,11 +780,11 @@ int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32
     HIPCHK(h, hipMalloc((void**)&da, 256 * sizeof(int)));
     HIPCHK(h, hipMalloc((void**)&db, 256 * sizeof(int)));
     HIPCHK(h, hipMalloc((void**)&dout, 256 * sizeof(int)));
-    HIPCHK(h, hipMemcpy(da, a, 256 * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(db, b, 256 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_sync(h, da, a, 256 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_sync(h, db, b, 256 * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(h, nbls_launch_probe_mfma_i8(h, da, db, dout));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, dout, 256 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, out, dout, 256 * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return NBLS_OK;
 }

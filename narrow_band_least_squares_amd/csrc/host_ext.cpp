@@ -11,8 +11,10 @@
 //       float repr (shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16, else exponent
 //       form), which is also the text str(numpy.float64) gives.  Needs no GPU result: the band loop calls
 //       it while the pass is running.
-//   build_stdict(mask (B, VL, MB) uint8, nwin (B,) int64, pair_idx (P, 2) int32, nchans, keys flat list)
-//       -> dict, entries in (band, window) order, 'size' right after the first band's entries (the
+//   build_stdict(mask (B, VL, MB) uint8, nwin (B,) int64, pair_idx (P, 2) int32, nchans, keys flat list,
+//                into dict | None, k0)
+//       -> dict (``into`` updated in place when given: the band groups of a pipelined call arrive one after the
+//       other; k0 = index in ``keys`` of this mask's first window), entries in (band, window) order, 'size' right after the first band's entries (the
 //       insertion order of the reference's merge loop).  Windows that dropped the SAME set of pairs
 //       share ONE read-only array object (the reference makes a fresh array per window; the values are
 //       equal, an in-place write raises instead of aliasing) — creating ~5*10^4 tiny arrays costs as
@@ -164,9 +166,11 @@ PyObject* time_keys(PyObject*, PyObject* args) {
 }
 
 PyObject* build_stdict(PyObject*, PyObject* args) {
-    PyObject *mask_obj, *nwin_obj, *pair_obj, *keys;
+    PyObject *mask_obj, *nwin_obj, *pair_obj, *keys, *into = Py_None;
     long nchans;
-    if (!PyArg_ParseTuple(args, "OOOlO", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys)) return nullptr;
+    Py_ssize_t k0 = 0;
+    if (!PyArg_ParseTuple(args, "OOOlO|On", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys, &into, &k0)) return nullptr;
+    if (into != Py_None && !PyDict_Check(into)) { PyErr_SetString(PyExc_TypeError, "into must be a dict or None"); return nullptr; }
     if (!PyList_Check(keys)) { PyErr_SetString(PyExc_TypeError, "keys must be a flat list of strings"); return nullptr; }
     PyArrayObject* mask = as_array(mask_obj, NPY_UINT8, 3, "mask");
     if (!mask) return nullptr;
@@ -186,17 +190,18 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
             if (nwin[b] < 0 || nwin[b] > VL) ok = false;
             total += (Py_ssize_t)nwin[b];
         }
-        if (!ok || PyList_GET_SIZE(keys) != total) {
+        if (!ok || k0 < 0 || PyList_GET_SIZE(keys) < k0 + total) {
             PyErr_SetString(PyExc_ValueError, "build_stdict: inconsistent shapes (mask / nwin / pair_idx / keys)");
         } else {
-            d = PyDict_New();
+            if (into != Py_None) { d = into; Py_INCREF(d); } else d = PyDict_New();
+            const bool fresh = d && PyDict_Size(d) == 0;     // 'size' goes right after the first band of the first group
             size_obj = PyLong_FromLong(nchans);
             std::vector<int32_t> dropped((size_t)P);
             std::unordered_map<std::string, PyObject*> patterns;     // mask bytes -> shared value array (owned)
             std::string pat((size_t)MB, '\0');
             const uint8_t* last = nullptr;                            // run of equal masks: skip the lookup
             PyObject* last_arr = nullptr;
-            Py_ssize_t k = 0;
+            Py_ssize_t k = k0;
             for (npy_intp b = 0; b < B && d; ++b) {
                 for (int64_t w = 0; w < nwin[b] && d; ++w, ++k) {
                     const uint8_t* mm = m + ((size_t)b * VL + (size_t)w) * MB;
@@ -238,10 +243,10 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                     if (!arr) continue;                 // nothing dropped in this window: no entry
                     if (PyDict_SetItem(d, PyList_GET_ITEM(keys, k), arr)) { Py_CLEAR(d); break; }
                 }
-                if (d && b == 0 && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+                if (d && b == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
             }
             for (auto& kv : patterns) Py_DECREF(kv.second);
-            if (d && B == 0 && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+            if (d && B == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
         }
     }
     Py_XDECREF(size_obj);

@@ -66,6 +66,7 @@ struct QArgs {
     int npg;                  // partner groups per sliding channel (1 up to 17 elements)
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
+    int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
     int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
@@ -403,13 +404,15 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     int* klo = cnt + 32;                            // interval in np.correlate index space
     int* khi = klo + 32;
     int* thS = khi + 32;                            // theta of the pair (f32 bits)
+    int* qctr = thS + 32;                           // [2] next lag group of each sliding channel (dynamic dealing), + 2 pad
     // energy tables for the lag-block pruning, f32 rounded UP: tails of the sliding channels, prefix sums of all
     const int NB = WP / 32 + 1;
-    float* tailT = (float*)(thS + 32);              // [NSL][NB + 1]  E_i[32k .. W)
+    float* tailT = (float*)(qctr + 4);              // [NSL][NB + 1]  E_i[32k .. W)
     float* cumT = tailT + NSL * (NB + 1);           // [N][NB + 1]    E_j[0 .. 32k)
     if (tid < 32) {
         gmax[tid] = (int)0x80000000;
         Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; thS[tid] = 0;
+        if (tid < 4) qctr[tid] = 0;
     }
 
     // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
@@ -628,11 +631,26 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      where the maximum usually is) establishes the maxima; far lag blocks of coherent windows are
     //      then never computed ----
     const int nw = 4;
-    for (int rnd = 0; chan_ok && rnd * nw < ngrp4; ++rnd) {
-        const int p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
-        if (p >= ngrp4) continue;
+    for (int rnd = 0; chan_ok; ++rnd) {
+        int p;
+        bool may_prune;
+        if (a.dyn) {
+            // dynamic dealing: the next lag group of this sliding channel goes to whichever of its four waves is
+            // free (ascending p: the small lags, where the maximum usually is, are started first; after pruning
+            // the groups cost very different amounts, a fixed deal leaves waves idle at the end)
+            int pp = 0;
+            if (lane == 0) pp = atomicAdd(&qctr[half], 1);
+            p = __builtin_amdgcn_readfirstlane(pp);
+            if (p >= ngrp4) break;
+            may_prune = p >= nw;
+        } else {
+            if (rnd * nw >= ngrp4) break;
+            p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
+            if (p >= ngrp4) continue;
+            may_prune = rnd > 0;
+        }
         const int D0 = TB * p * step;
-        if (rnd > 0 && !(NBLS_ABL(32))) {
+        if (may_prune && !NBLS_ABL(32)) {
             bool prunable = true;
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
@@ -1055,8 +1073,8 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     // LDS, else one sliding channel (4 waves, N-1 images)
     // + running maxima and merge scalars (6 x 32 ints); the f32 energy tables of the pruning test are added by
     // the caller when they still fit (nbls_screen_tables)
-    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 64;
-    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 64;
+    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 64;
+    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 64;
     const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
     if (lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
@@ -1095,6 +1113,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.vector_len = h->vector_len;
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
+    a.dyn = h->opt.screen_static ? 0 : 1;
     a.ablate = h->opt.ablate;
     a.stamps = h->opt.screen_stamps ? h->d_stamps : nullptr;
     {

@@ -29,15 +29,28 @@ def default_device():
     return 0
 
 
-def get_handle(device=None):
-    """Per-(process, device) handle, created lazily so that a fork before first use is safe."""
+def get_handle(device=None, slot=0):
+    """Per-(process, device, slot) handle, created lazily so that a fork before first use is safe.  Slots > 0
+    are further handles (own stream, own buffers) on the same GPU: the band groups of a pipelined call."""
     dev = default_device() if device is None else int(device)
-    key = (os.getpid(), dev)
+    key = (os.getpid(), dev, int(slot))
     h = _handles.get(key)
     if h is None:
         h = Handle(dev)
         _handles[key] = h
     return h
+
+
+def pipeline_groups(nwin):
+    """Into how many band groups a call is cut (``NBLS_PIPELINE_GROUPS`` overrides).  Each group is its own
+    asynchronous pass on its own handle of the same GPU: while the GPU works on group k, the host designs the
+    filters of group k+1, and later turns the finished groups' weights into the dropped-element dictionary
+    while the remaining groups are still being computed.  Small calls are one group."""
+    env = os.environ.get('NBLS_PIPELINE_GROUPS')
+    nb = len(nwin)
+    if env:
+        return max(1, min(nb, int(env)))
+    return max(1, min(4, nb, int(np.sum(nwin)) // 20000))
 
 
 def stream_to_array(st):
@@ -168,11 +181,14 @@ def prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_t
                 sos_ret=sos_ret, alpha=alpha, npairs=xij.shape[0], mask_bytes=(xij.shape[0] + 7) // 8)
 
 
-def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0):
+def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0, trace_from=None):
     """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
-    None = all) on handle ``h``.  Returns as soon as the kernels are queued."""
+    None = all) on handle ``h``.  Returns as soon as the kernels are queued.  ``trace_from``: another handle of
+    the same GPU that already holds this trace (device-to-device copy instead of a second upload)."""
     if upload:
-        if isinstance(data, np.ndarray):
+        if trace_from is not None and trace_from is not h:
+            h.set_trace_from(trace_from)
+        elif isinstance(data, np.ndarray):
             h.set_trace(data, prep.fs)
         else:
             h.set_trace_rows(data, prep.fs)
@@ -213,7 +229,7 @@ def split_block(block, nbands, vector_len, mask_bytes):
 def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
             filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
             want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
-            upload=True, window_slice=None, host_overlap=None):
+            upload=True, window_slice=None, host_overlap=None, group_done=None, groups=None):
     """Run the hot path for a list of bands on one GPU.
 
     window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
@@ -222,49 +238,89 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     data (N, npts) raw traces — a 2-D array or a list of N rows (uploaded from where they lie);
     band_edges [(fmin, fmax), ...]; winlens [seconds per band].
     prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
-    host_overlap: callable(partial BandBatch) run on the host between the asynchronous launch of the
-    pass and the wait for it (filter responses, key strings, ...: host work that hides behind the GPU).
-    More bands than fit in HBM at once are processed in consecutive passes."""
-    nchans, npts = _shape_of(data)
-    cap = max_bands_per_pass(nchans, npts)
-    if len(band_edges) > cap and not prefiltered:
-        if vector_len is None:
-            vector_len = max(1, max(planner.window_plan(npts, fs, wl, winover)[2] for wl in winlens))
-        parts = []
-        for b0 in range(0, len(band_edges), cap):
-            parts.append(process(data, fs, t0_datenum, rij, band_edges[b0:b0 + cap], winlens[b0:b0 + cap], winover,
-                                 alpha, filter_type, filter_order, filter_ripple, vector_len, device, xcorr_impl,
-                                 want_lag, want_cmax, want_z, False, handle, upload and b0 == 0, window_slice))
-        first = parts[0]
 
-        def cat(name):
-            vals = [getattr(p, name) for p in parts]
-            return None if vals[0] is None else np.concatenate(vals, axis=0)
-        out = BandBatch(vel=cat('vel'), baz=cat('baz'), mdccm=cat('mdccm'), sigma_tau=cat('sigma_tau'),
-                        nwin=cat('nwin'), t=cat('t'), mask=cat('mask'), lag=cat('lag'), cmax=cat('cmax'),
-                        z=cat('z'), sos=[s for p in parts for s in p.sos], W=cat('W'), inc=cat('inc'),
-                        pair_idx=first.pair_idx, xij=first.xij, nchans=nchans, alpha=alpha, handle=first.handle,
-                        lts=first.lts, fs=fs)
-        if host_overlap is not None:
-            host_overlap(out)
-        return out
-    prep = prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
-                   filter_ripple, vector_len, prefiltered)
-    h = handle if handle is not None else get_handle(device)
-    launch(h, data, prep, upload=upload, window_slice=window_slice, xcorr_impl=xcorr_impl)
-    # asynchronous from here: the host work below hides behind the pass
-    res = BandBatch(vel=None, baz=None, mdccm=None, sigma_tau=None, nwin=prep.nwin.astype(int),
-                    t=all_window_times(prep, t0_datenum), mask=None, lag=None, cmax=None, z=None, sos=prep.sos_ret,
-                    W=prep.W, inc=prep.inc, pair_idx=prep.pair_idx, xij=prep.xij, nchans=nchans, alpha=alpha, handle=h,
-                    lts=prep.lts is not None, fs=fs)
+    Host/GPU overlap: the bands are cut into ``groups`` contiguous groups (``pipeline_groups``), each an
+    asynchronous pass on its own handle of the same GPU, queued as soon as its filters are designed.
+    ``host_overlap(res)`` runs once everything is queued (filter responses, key strings: host work that needs
+    no GPU result); ``group_done(res, b0, b1)`` runs as soon as the rows of bands [b0, b1) have landed, while
+    later groups are still being computed (the caller builds its dictionary there).
+    More bands than fit in HBM at once are processed in consecutive rounds."""
+    nchans, npts = _shape_of(data)
+    nb = len(band_edges)
+    cap = max_bands_per_pass(nchans, npts)
+    W, inc, nwin = [np.empty(nb, dtype=t) for t in (np.int32, np.int32, np.int64)]
+    for b in range(nb):
+        W[b], inc[b], nwin[b] = planner.window_plan(npts, fs, winlens[b], winover)
+    if vector_len is None:
+        vector_len = max(1, int(nwin.max()))
+    if nwin.max() > vector_len:
+        raise ValueError('could not broadcast %d windows into result rows of length %d '
+                         '(vector_len too small for this band)' % (int(nwin.max()), vector_len))
+    check_elements(nchans, alpha)
+    ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin))
+    ngroups = max(1, min(ngroups, nb))
+    # contiguous band groups of about equal unit counts
+    cum = np.concatenate(([0], np.cumsum(nwin)))
+    cuts = [0]
+    for g in range(1, ngroups):
+        b = int(np.searchsorted(cum, cum[-1] * g / ngroups))
+        cuts.append(min(max(b, cuts[-1] + 1), nb - (ngroups - g)))
+    cuts.append(nb)
+    bounds = [(cuts[g], cuts[g + 1]) for g in range(ngroups)]
+    if max(b1 - b0 for b0, b1 in bounds) * ngroups > cap:           # HBM budget: consecutive rounds of <= cap bands
+        bounds = [(b0, min(b0 + cap, nb)) for b0 in range(0, nb, cap)]
+        sequential = True
+    else:
+        sequential = False
+
+    P = nchans * (nchans - 1) // 2
+    MB = (P + 7) // 8
+    grids = np.zeros((4, nb, vector_len))
+    mask = np.zeros((nb, vector_len, MB), dtype=np.uint8)
+    lag = np.zeros((nb, vector_len, P), dtype=np.int32) if want_lag else None
+    cmax = np.zeros((nb, vector_len, P)) if want_cmax else None
+    z = np.zeros((nb, vector_len, 2)) if want_z else None
+    res = BandBatch(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], nwin=nwin.astype(int), t=None,
+                    mask=mask, lag=lag, cmax=cmax, z=z, sos=[], W=W, inc=inc, pair_idx=None, xij=None,
+                    nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs)
+
+    def collect(h, b0, b1):
+        out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
+        grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
+        mask[b0:b1] = out['mask']
+        if want_lag or want_cmax or want_z:
+            ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
+            for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
+                if arr is not None:
+                    arr[b0:b1] = ext[name]
+        if group_done is not None:
+            group_done(res, b0, b1)
+
+    def finish_skeleton(prep):
+        res.pair_idx, res.xij = prep.pair_idx, prep.xij
+        tt = np.zeros((nb, vector_len))
+        for b in range(nb):
+            tt[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
+        res.t = tt
+
+    launched = []
+    for g, (b0, b1) in enumerate(bounds):
+        prep = prepare(nchans, npts, fs, rij, band_edges[b0:b1], winlens[b0:b1], winover, alpha, filter_type,
+                       filter_order, filter_ripple, vector_len, prefiltered)
+        res.sos.extend(prep.sos_ret)
+        h = handle if handle is not None else get_handle(device, 0 if sequential else g)
+        if sequential and launched:               # one handle, one plan at a time: finish the previous round first
+            collect(*launched.pop())
+        launch(h, data, prep, upload=upload, window_slice=window_slice, xcorr_impl=xcorr_impl,
+               trace_from=launched[0][0] if (launched and not sequential) else None)
+        launched.append((h, b0, b1))
+        res.handle = h
+    finish_skeleton(prep)
+    # everything is queued: host work that needs no GPU result hides behind the passes
     if host_overlap is not None:
         host_overlap(res)
-    out = h.fetch_packed()                        # waits for the pass; ONE D2H copy (grids + weight mask)
-    res.vel, res.baz, res.mdccm, res.sigma_tau, res.mask = (out['vel'], out['baz'], out['mdccm'], out['sigma_tau'],
-                                                            out['mask'])
-    if want_lag or want_cmax or want_z:
-        ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
-        res.lag, res.cmax, res.z = ext['lag'], ext['cmax'], ext['z']
+    for item in launched:
+        collect(*item)
     return res
 
 
@@ -287,7 +343,7 @@ def _py_time_keys(t, nwin, prefixes=None):
     return out
 
 
-def stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
+def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
     """lts_array's dropped-element dictionary for ALL bands of a pass from the packed weight mask
     (B, VL, ceil(P/8)): key (``keys[b][w]``, see ``time_keys``) -> 1-based element numbers of both
     members of every zero-weight pair (first members, then second members), only for windows that
@@ -298,14 +354,17 @@ def stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
     Windows that dropped the SAME set of pairs share ONE read-only array (the reference makes a fresh
     array per window; the values are equal, and an in-place write raises instead of aliasing): creating
     ~5*10^4 tiny arrays per call costs as much host time as the whole GPU pass.  With the C++ helper
-    module built, one C++ pass does the work; the NumPy form below is its equivalent."""
+    module built, one C++ pass does the work; the NumPy form below is its equivalent.
+
+    ``into`` / ``k0``: update an existing dictionary with the bands of one group of a pipelined call (``k0`` =
+    index in ``keys`` of this mask's first window); 'size' is only placed by the call that starts the dictionary."""
     if _hostext is not None:
         return _hostext.build_stdict(np.ascontiguousarray(mask, dtype=np.uint8), np.ascontiguousarray(nwin, dtype=np.int64),
-                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys)
-    return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys)
+                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys, into, int(k0))
+    return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into, k0)
 
 
-def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
+def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
     pair_idx = np.asarray(pair_idx)
     P = len(pair_idx)
     B, VL, MB = mask.shape
@@ -314,7 +373,9 @@ def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
     m = mask[valid]                                              # (U, MB), (band, window) order
     full = np.packbits(np.ones(P, dtype=np.uint8), bitorder='little')
     hit = ((m & full[None, :]) != full[None, :]).any(axis=1)
-    stdict = {}
+    stdict = {} if into is None else into
+    fresh = len(stdict) == 0
+    keys = keys[k0:k0 + len(hit)] if (k0 or len(keys) != len(hit)) else keys
     n = int(np.count_nonzero(hit))
     if n:
         sel = np.ascontiguousarray(m[hit])
@@ -335,10 +396,12 @@ def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys):
         pieces = operator.itemgetter(*inv.ravel().tolist())(pats) if n > 1 else (pats[0],)
         items = zip(itertools.compress(keys, hit.tolist()), pieces)
         # key order of the reference's merge loop: the first band's time keys, 'size', then the other bands
-        stdict = dict(itertools.islice(items, int(np.count_nonzero(hit[:int(nwin[0])]))))
-        stdict['size'] = nchans
+        if fresh:
+            stdict.update(itertools.islice(items, int(np.count_nonzero(hit[:int(nwin[0])]))))
+            stdict['size'] = nchans
         stdict.update(items)
-    stdict['size'] = nchans
+    if fresh:
+        stdict['size'] = nchans
     return stdict
 
 

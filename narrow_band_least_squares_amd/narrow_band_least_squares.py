@@ -82,9 +82,16 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
             _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
         if ALPHA < 1.0 and want_keys:
             res.keys = engine.time_keys(res.t, res.nwin, key_prefixes)
+            res.stdict = {}
+
+    def group_done(res, b0, b1):
+        # the dropped-element dictionary of the bands whose rows just landed, while later groups are still running
+        if ALPHA < 1.0 and want_keys:
+            engine.stdict_from_mask(res.mask[b0:b1], res.nwin[b0:b1], res.pair_idx, res.nchans, res.keys,
+                                    into=res.stdict, k0=int(np.sum(res.nwin[:b0])))
 
     res = engine.process(rows, fs, t0, rij, edges, winlens, WINOVER, ALPHA, FILTER_TYPE, FILTER_ORDER,
-                         FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side)
+                         FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side, group_done=group_done)
     return res, w_rows, h_rows
 
 
@@ -114,7 +121,7 @@ def narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_lis
         stdict_all = None
         sig_tau_array = res.sigma_tau
     else:
-        stdict_all = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
+        stdict_all = res.stdict                  # built group by group while the GPU was still working
         sig_tau_array = np.zeros_like(res.sigma_tau)
     return (res.vel, res.baz, res.mdccm, res.t, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
@@ -133,7 +140,7 @@ def narrow_band_loop(ii, freqlist, FREQ_BAND_TYPE, freq_resp_list, st, FILTER_TY
         stdict_times = None
         stdict_elements = None
     else:
-        sd = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys)
+        sd = res.stdict
         temp_array = np.array(list(sd.items()), dtype=object)
         stdict_times = temp_array[:, 0]
         stdict_elements = temp_array[:, 1]

@@ -359,6 +359,26 @@ def test_band_passes_when_hbm_budget_is_small(monkeypatch):
     assert len(split.sos) == len(edges)
 
 
+def test_pipelined_band_groups_equal_one_pass(monkeypatch):
+    """The whole call cut into 1, 2 and 4 band groups (concurrent passes on several handles of the same GPU,
+    dictionary built group by group): identical tuples, identical key order."""
+    c = _cfg('cfg2', 0.3)
+    fr = np.logspace(-2, 1, 32)
+    w = np.zeros(32)
+    args = (c['WINLEN_list'], 0.5, 0.5, c['st'], None, None, c['NBANDS'], w, w, c['freqlist'], c['band_type'], fr,
+            'butter', 2, 0.01)
+    outs = []
+    for g in ('1', '2', '4'):
+        monkeypatch.setenv('NBLS_PIPELINE_GROUPS', g)
+        outs.append(narrow_band_least_squares(*args, rij=c['rij']))
+    for o in outs[1:]:
+        for i in (0, 1, 2, 3, 5, 7, 8):
+            np.testing.assert_array_equal(o[i], outs[0][i])
+        assert o[6] == outs[0][6] and list(o[4].keys()) == list(outs[0][4].keys())
+        for k in outs[0][4]:
+            np.testing.assert_array_equal(o[4][k], outs[0][4][k])
+
+
 def test_window_slices_add_up_to_the_full_run():
     """Window sharding (fewer bands than GPUs): the slices of the windows processed separately are
     disjoint, keep their global row index and add up to the unsliced run bit for bit."""

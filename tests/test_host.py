@@ -265,6 +265,16 @@ def test_host_extension_matches_python_equivalents():
                 if k != 'size':
                     np.testing.assert_array_equal(got[k], exp[k])
                     assert got[k].dtype == exp[k].dtype and not got[k].flags.writeable
+            # built group by group (pipelined call): same dictionary, same order
+            for impl in (ext.build_stdict, engine._py_stdict_from_mask):
+                inc = {}
+                for b0, b1 in ((0, 2), (2, 3), (3, 5)):
+                    ret = impl(mask[b0:b1], nwin[b0:b1], pair_idx, nch, keys, inc, int(nwin[:b0].sum()))
+                    assert ret is inc
+                assert list(inc.keys()) == list(exp.keys())
+                for k in exp:
+                    if k != 'size':
+                        np.testing.assert_array_equal(inc[k], exp[k])
     with pytest.raises(ValueError):
         ext.build_stdict(np.zeros((1, 2, 4), np.uint8), np.array([2]), planner.pair_table(8), 8, ['a'])
 

@@ -1,49 +1,64 @@
-"""Stage timings of one named configuration on the GPU (developer tool)."""
+"""Stage timings of one named configuration on the GPU (developer tool): all bands as ONE pass, planned once,
+executed back to back.
+
+    python tools/quick_time.py cfg3 [scale] [reps] [key=value ...]      # key=value -> Handle.set_option
+    NBLS_LIB=narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so python tools/quick_time.py cfg3 1 3 screen_stamps=1
+
+With the developer build (`make -C narrow_band_least_squares_amd/csrc dev`) the options screen_stamps / lts_stamps
+print the in-kernel phase stamps, and ablate=<bits> skips kernel parts (results wrong, timing only)."""
 import sys
-import time
 
 import numpy as np
 
 sys.path.insert(0, __file__.rsplit('/', 2)[0])
-from narrow_band_least_squares_amd import engine, synthetic, planner  # noqa: E402
+from narrow_band_least_squares_amd import engine, synthetic  # noqa: E402
 
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
-    scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-    impl = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    pos = [a for a in sys.argv[1:] if '=' not in a]
+    opts = dict(a.split('=') for a in sys.argv[1:] if '=' in a)
+    name = pos[0] if pos else 'cfg3'
+    scale = float(pos[1]) if len(pos) > 1 else 1.0
+    reps = int(pos[2]) if len(pos) > 2 else 3
+    impl = int(opts.pop('impl', 0))
+    nbands = int(opts.pop('bands', 0))
     c = synthetic.build_config(name, scale=scale)
-    data, fs, t0 = engine.stream_to_array(c['st'])
+    rows, fs, t0 = engine.stream_rows(c['st'])
     step = 2 if c['band_type'] == '2_octave_over' else 1
-    edges = [(c['freqlist'][i], c['freqlist'][i + step]) for i in range(c['NBANDS'])]
+    nb = nbands or c['NBANDS']
+    edges = [(c['freqlist'][i], c['freqlist'][i + step]) for i in range(nb)]
     h = engine.get_handle()
+    for k, v in opts.items():
+        h.set_option(k, int(v))
     h.set_profiling(True)
+    prep = engine.prepare(len(rows), len(rows[0]), fs, c['rij'], edges, c['WINLEN_list'][:nb], c['overlap'], c['alpha'],
+                          c['ftype'], c['order'], c['ripple'])
+    engine.launch(h, rows, prep, xcorr_impl=impl)
+    h.sync()
+    U = int(prep.nwin.sum())
     for r in range(reps):
-        t = time.time()
-        res = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'], c['overlap'], c['alpha'],
-                             c['ftype'], c['order'], c['ripple'], xcorr_impl=impl)
-        wall = time.time() - t
+        h.execute()
+        h.sync()
         tm = h.timings()
-        U = int(res.nwin.sum())
-        print('%s scale=%g impl=%d units=%d wall=%.3fs filter=%.2fms xcorr=%.2fms solve=%.2fms total=%.2fms -> %.0f solves/s (device)'
-              % (name, scale, impl, U, wall, tm['filter_ms'], tm['xcorr_ms'], tm['solve_ms'], tm['total_ms'],
-                 U / (tm['total_ms'] * 1e-3)), flush=True)
-    if impl == 3:
+        print('%s scale=%g units=%d filter=%.2f quantize=%.2f screen=%.2f verify=%.2f solve=%.2f total=%.2f ms -> %.0f solves/s (device)'
+              % (name, scale, U, tm['filter_ms'], tm['quantize_ms'], tm['screen_ms'], tm['verify_ms'], tm['solve_ms'],
+                 tm['total_ms'], U / (tm['total_ms'] * 1e-3)), flush=True)
+    if tm['xcorr_impl'] == 3:
         print('screen stats (last batch):', h.screen_stats())
-    import os
-    if os.environ.get('NBLS_SCREEN_STAMPS') == '1':
+    if opts.get('screen_stamps'):
         st = h.screen_stamps()
         tot = st['total'] or 1.0
         print('screen stamps (mean cycles per workgroup, last batch):',
               {k: '%.0f (%.0f%%)' % (v, 100 * v / tot) for k, v in st.items()})
-    if os.environ.get('NBLS_LTS_STAMPS') == '1':
+    if opts.get('lts_stamps'):
         st = h.lts_stamps()
         tot = st['total'] or 1.0
         print('lts stamps (mean cycles per wave):', {k: '%.0f (%.0f%%)' % (v, 100 * v / tot) for k, v in st.items()})
-    n = int(res.nwin[len(edges) // 2])
-    print('mid band: median baz %.3f vel %.4f mdccm %.3f' % (np.nanmedian(res.baz[len(edges) // 2, :n]),
-          np.nanmedian(res.vel[len(edges) // 2, :n]), np.nanmedian(res.mdccm[len(edges) // 2, :n])))
+    out = h.fetch_packed()
+    mid = nb // 2
+    n = int(prep.nwin[mid])
+    print('mid band: median baz %.3f vel %.4f mdccm %.3f' % (np.nanmedian(out['baz'][mid, :n]), np.nanmedian(out['vel'][mid, :n]),
+                                                            np.nanmedian(out['mdccm'][mid, :n])))
 
 
 if __name__ == '__main__':
