@@ -79,6 +79,22 @@ struct QArgs {
     double* cmax;
 };
 
+// XCD-aware item order of the streaming kernels (quantize, verify).  Workgroups are dealt round-robin to the 8
+// XCDs (blockIdx % 8), each with its own L2.  Consecutive windows of a band overlap (by half at the usual 50 %):
+// every XCD therefore takes ONE contiguous range of the items, ordered so that neighbours share samples, and
+// walks it in dispatch order — the second reader of an overlap finds it in that XCD's L2 instead of fetching it
+// from HBM again.  -> item index, or -1 for the padding at the end of an XCD's range.
+__device__ inline int xcd_item(int block, int per_block, int sub, int total) {
+    const int xcd = block & 7, slot = block >> 3;
+    const int share = (total + 7) >> 3;
+    const int it = xcd * share + slot * per_block + sub;
+    return (slot * per_block + sub < share && it < total) ? it : -1;
+}
+__host__ inline int xcd_grid(int per_block, int total) {
+    const int share = (total + 7) >> 3;
+    return 8 * ((share + per_block - 1) / per_block);
+}
+
 // ------------------------------------------------------------------ 1. quantize
 // One wave per (unit, channel).  The window is read once from global memory with lane-contiguous
 // loads into the wave's LDS slab (max |x| and sum x^2 on the way); each lane then quantises runs of 8
@@ -90,10 +106,11 @@ __device__ inline int qpad(int n) { return n + (n >> 3); }
 __global__ __launch_bounds__(256) void quantize_kernel(QArgs a) {
     extern __shared__ double qsm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * (blockDim.x >> 6) + wv;      // 1..4 waves per workgroup (what the slabs leave room for)
     const int N = a.nchans;
-    if (item >= a.nu * N) return;
-    const int ul = item / N, ch = item % N;
+    // (channel, unit) in channel-major order: neighbours are consecutive windows of one channel (see xcd_item)
+    const int item = xcd_item(blockIdx.x, blockDim.x >> 6, wv, a.nu * N);     // 1..4 waves per workgroup (what the slabs leave room for)
+    if (item < 0) return;
+    const int ch = item / a.nu, ul = item - ch * a.nu;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
@@ -206,10 +223,10 @@ template <int G>
 __global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
     extern __shared__ double qsm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wv;
     const int N = a.nchans;
-    if (item >= a.nu * N) return;
-    const int ul = item / N, ch = item % N;
+    const int item = xcd_item(blockIdx.x, 4, wv, a.nu * N);       // channel-major (channel, unit), see xcd_item
+    if (item < 0) return;
+    const int ch = item / a.nu, ul = item - ch * a.nu;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
     const int w = a.unit_win[u];                            // window index inside the band (global)
@@ -904,7 +921,8 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     extern __shared__ double vsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
     const int P = a.npairs, N = a.nchans;
-    const int ul = blockIdx.x;
+    const int ul = xcd_item(blockIdx.x, 1, 0, a.nu);        // consecutive windows stay on one XCD (see xcd_item)
+    if (ul < 0) return;
     const int u = a.u0 + ul;
     const int band = a.unit_band[u];
     const int w = a.unit_win[u];                            // window index inside the band (global)
@@ -1160,9 +1178,9 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
             const size_t qlds = (size_t)4 * (a.WP / 8 + 8) * sizeof(double);
             const bool slab = h->opt.quantize_slab != 0;                        // option: the LDS-slab form
             if (gpl <= 4 && !slab)
-                hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
+                hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
             else if (gpl <= 8 && !slab)
-                hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3((a.nu * N + 3) / 4), dim3(256), qlds, h->stream, a);
+                hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
             else {
                 // one LDS slab per wave: as many waves per workgroup (<= 4) as fit a CU's 160 KB
                 const size_t slab = (size_t)(a.WP + a.WP / 4 + 8) * sizeof(double);
@@ -1173,7 +1191,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
                     hipError_t qe = hipFuncSetAttribute((const void*)quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slab * nwq));
                     if (qe != hipSuccess) return qe;
                 }
-                hipLaunchKernelGGL(quantize_kernel, dim3((a.nu * N + nwq - 1) / nwq), dim3(64 * nwq), slab * nwq, h->stream, a);
+                hipLaunchKernelGGL(quantize_kernel, dim3(xcd_grid(nwq, a.nu * N)), dim3(64 * nwq), slab * nwq, h->stream, a);
             }
         }
         if (ev) (void)hipEventRecord(ev[1], h->stream);
@@ -1181,7 +1199,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(256 * a.nsl), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vlds <= 80 * 1024)
-            hipLaunchKernelGGL(verify_lds_kernel, dim3(a.nu), dim3(512), vlds, h->stream, a);
+            hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(512), vlds, h->stream, a);
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);

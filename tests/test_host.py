@@ -432,3 +432,55 @@ def test_vincenty_against_published_constants():
     dy = np.radians(0.005) * M
     dx = np.radians(0.01) * Nn * np.cos(lat)
     assert abs(d12 - np.hypot(dx, dy)) < 1e-4 * d12
+
+
+def test_host_extension_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY.md §5 (sanitizers, host side only): csrc/host_ext.cpp built with -fsanitize=address,undefined and
+    driven through its whole surface — key text, dictionary assembly (fresh, incremental, > 8 mask bytes), every
+    error path — in a child interpreter with libasan preloaded.  No report, exit code 0."""
+    import subprocess
+    src = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'host_ext.cpp')
+    import sysconfig
+    out = str(tmp_path / '_nbls_host.so')
+    cmd = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+           '-I' + sysconfig.get_paths()['include'], '-I' + np.get_include(), src, '-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    libasan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import _nbls_host as ext
+rng = np.random.default_rng(0)
+for x in list(rng.standard_normal(2000) * 10.0 ** rng.integers(-30, 30, 2000)) + [0.0, -0.0, float('inf'), float('nan'), 5e-324, 1.7976931348623157e308]:
+    assert ext.float_repr(float(x)) == repr(float(x))
+for nch in (3, 8, 16, 32):
+    pair = np.array([(i, j) for i in range(nch - 1) for j in range(i + 1, nch)], dtype=np.int32)
+    P = len(pair); B, VL = 4, 19
+    nwin = np.array([19, 0, 7, 18])
+    w = (rng.random((B, VL, P)) > 0.1).astype(np.uint8)
+    mask = np.packbits(w, axis=-1, bitorder='little')
+    t = 17884.0 + rng.random((B, VL))
+    keys = ext.time_keys(t, nwin, ['%%02d_' %% (b + 1) for b in range(B)])
+    assert len(keys) == nwin.sum() and len(ext.time_keys(t, nwin, None)) == nwin.sum()
+    d = ext.build_stdict(mask, nwin, pair, nch, keys)
+    inc = {}
+    for b0, b1 in ((0, 1), (1, 3), (3, 4)):
+        ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair, nch, keys, inc, int(nwin[:b0].sum()))
+    assert list(inc) == list(d) and d['size'] == nch
+    for bad in (lambda: ext.build_stdict(mask, nwin[:2], pair, nch, keys), lambda: ext.build_stdict(mask, nwin, pair, nch, keys[:3]),
+                lambda: ext.build_stdict(np.concatenate((mask, mask), axis=-1), nwin, pair, nch, keys), lambda: ext.build_stdict(mask, nwin, pair, nch, keys, [], 0),
+                lambda: ext.build_stdict(mask, nwin, pair, nch, keys, {}, -1), lambda: ext.time_keys(t, nwin + 100, None),
+                lambda: ext.time_keys(t, nwin, ['a']), lambda: ext.time_keys(t[0], nwin, None), lambda: ext.float_repr('x')):
+        try:
+            bad()
+        except (ValueError, TypeError):
+            pass
+        else:
+            raise SystemExit('an invalid call was accepted')
+print('SAN_OK')
+''' % str(tmp_path)
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS='detect_leaks=0', PYTHONMALLOC='malloc')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'SAN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-4000:]
