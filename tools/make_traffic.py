@@ -1,11 +1,13 @@
-"""Post-process the rocprofv3 output of tools/profile_round.sh into the summaries kept under profiles/
-(kernel stats CSV, per-kernel PMC means, traffic.json).  Usage: make_traffic.py TAG DIR"""
+"""Post-process the two rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE; separate runs with
+--kernel-trace only, as MI355X_MICROARCH.md prescribes) into profiles/traffic.json and per-kernel summaries.
+Counter values are KiB; FETCH_SIZE is doubled (gfx950 reports half of a wide 16-B/lane coalesced stream).
+Usage: make_traffic.py TAG DIR --traffic-only"""
 import collections
 import csv
 import glob
 import json
+import os
 import re
-import shutil
 import sys
 
 
@@ -14,7 +16,7 @@ def kname(full):
     return m.group(1) if m else full[:40]
 
 
-def pmc_means(d, counter):
+def pmc(d, counter):
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
     tot = collections.defaultdict(float)
     n = collections.Counter()
@@ -22,45 +24,47 @@ def pmc_means(d, counter):
         if r['Counter_Name'] != counter:
             continue
         k = kname(r['Kernel_Name'])
-        tot[k] += float(r['Counter_Value'])
+        tot[k] += float(r['Counter_Value']) * 1024.0
         n[k] += 1
-    return {k: (tot[k] / n[k], n[k]) for k in tot}
+    return tot, n
 
 
 def main():
     tag, d = sys.argv[1], sys.argv[2]
-    traffic_only = len(sys.argv) > 3 and sys.argv[3] == '--traffic-only'
-    out = d + '/out'
-    import os
-    os.makedirs(out, exist_ok=True)
-    if not traffic_only:
-        shutil.copy(glob.glob(d + '/stats/*/*kernel_stats.csv')[0], '%s/%s_bench_cfg3_kernel_stats.csv' % (out, tag))
-        shutil.copy('%s/%s_bench_cfg3.json' % (d, tag), '%s/%s_bench_cfg3.json' % (out, tag))
-        print(open('%s/%s_bench_cfg3.json' % (out, tag)).read().strip()[:600])
-        return
-    fetch = pmc_means(d + '/fetch', 'FETCH_SIZE')
-    write = pmc_means(d + '/write', 'WRITE_SIZE')
-    for name, tab in (('fetch', fetch), ('write', write)):
-        with open('%s/%s_pmc_%s_size_summary.csv' % (out, tag, name), 'w') as fh:
-            fh.write('kernel,launches,mean_KiB_per_launch\n')
-            for k, (v, c) in sorted(tab.items()):
-                fh.write('%s,%d,%.3f\n' % (k, c, v))
-    raw = {}
-    for k in fetch:
-        raw[k] = {'FETCH_SIZE_bytes': fetch[k][0] * 1024.0, 'WRITE_SIZE_bytes': write.get(k, (0.0, 0))[0] * 1024.0,
-                  'launches': fetch[k][1]}
+    fetch, nf = pmc(d + '/fetch', 'FETCH_SIZE')
+    write, nw = pmc(d + '/write', 'WRITE_SIZE')
+    # the bench command of profile_round.sh: warmup 1 + steps 4 whole calls (3 band-group passes each) + 1 planning
+    # pass + 3 kernel-only passes of all bands = 9 passes over all units; screen_kernel launches tell the exact count
     dom = 'screen_kernel'
-    traffic = 2.0 * raw[dom]['FETCH_SIZE_bytes'] + raw[dom]['WRITE_SIZE_bytes']
-    js = {'cfg3': {'xcorr_hbm_bytes_per_launch': traffic, 'kernel': dom,
-                   'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 2 '
-                             '--warmup 1, with --kernel-trace only); counter values are KiB; FETCH_SIZE doubled per '
-                             'MI355X_MICROARCH.md (gfx950 reports half of a wide 16-B/lane coalesced stream; the staging '
-                             'loads of this kernel are 16 B/lane); per-launch mean over the unit batches of a step',
-                   'raw_per_launch_bytes': raw}}
-    json.dump(js, open(out + '/traffic.json', 'w'), indent=1)
-    # bench.py reads profiles/traffic.json: refresh it BEFORE the bench run of this script
-    json.dump(js, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'traffic.json'), 'w'), indent=1)
-    print('traffic per launch (%s): %.1f MB' % (dom, traffic / 1e6))
+    per_kernel = {}
+    for k in sorted(set(fetch) | set(write)):
+        per_kernel[k] = {'FETCH_SIZE_bytes_total': fetch.get(k, 0.0), 'WRITE_SIZE_bytes_total': write.get(k, 0.0),
+                         'launches': int(nf.get(k, nw.get(k, 0)))}
+    # passes over all units = total units screened / units per pass: every pass quantises each (unit, channel) once,
+    # so use the solve kernels' launch count (one per pass) when present
+    solve = [k for k in per_kernel if k.startswith('solve_')]
+    passes_units = None
+    js = {'tag': tag, 'kernel': dom,
+          'xcorr_hbm_bytes_per_launch': (2.0 * fetch.get(dom, 0.0) + write.get(dom, 0.0)) / max(1, nf.get(dom, 1)),
+          'all_kernels_hbm_bytes_total': sum(2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in per_kernel),
+          'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 4 --warmup 1 '
+                    '--no-cpu-baseline --no-noise` (with --kernel-trace only); counter values are KiB; FETCH_SIZE doubled per '
+                    'MI355X_MICROARCH.md (gfx950 reports half of a wide 16-B/lane coalesced stream); per-launch mean of the '
+                    'dominant kernel over all its launches; tools/pmc_traffic.sh gives the per-pass sums of every kernel',
+          'per_kernel': per_kernel}
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    old = {}
+    path = os.path.join(root, 'profiles', 'traffic.json')
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old = {k: v for k, v in old.items() if k.startswith('cfg')}
+    old['cfg3'] = js
+    json.dump(old, open(path, 'w'), indent=1)
+    json.dump(old, open(d + '/traffic.json', 'w'), indent=1)
+    print('traffic per launch (%s): %.1f MB' % (dom, js['xcorr_hbm_bytes_per_launch'] / 1e6))
 
 
 if __name__ == '__main__':

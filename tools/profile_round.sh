@@ -1,13 +1,19 @@
-# Evidence for profiles/: run through gpurun from the repo root:  gpurun -- 'bash tools/profile_round.sh r01'
-# 1./2. FETCH_SIZE / WRITE_SIZE PMC passes -> traffic.json, 3. bench JSON line (reads that traffic.json),
-# 4. rocprofv3 kernel stats of the same command.
-TAG=${1:-r01}
+# Evidence for profiles/: run through gpurun from the repo root:  gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
+#   1./2. FETCH_SIZE / WRITE_SIZE PMC passes of the bench command (cfg-3) -> traffic.json (per kernel, per pass)
+#   3.    bench JSON line of every configuration (cfg-3 reads that traffic.json)
+#   4.    rocprofv3 --kernel-trace --stats of the same bench command per configuration
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof
-rm -rf gpurun_out/prof/stats gpurun_out/prof/fetch gpurun_out/prof/write
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/fetch.log 2>&1 || exit 3
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/write.log 2>&1 || exit 4
-python tools/make_traffic.py ${TAG} gpurun_out/prof --traffic-only || exit 5
-python bench.py --steps 5 --warmup 1 > gpurun_out/prof/${TAG}_bench_cfg3.json 2> gpurun_out/prof/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof/stats.log 2>&1 || exit 2
-python tools/make_traffic.py ${TAG} gpurun_out/prof
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+BENCH="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-noise"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1 || exit 3
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1 || exit 4
+python tools/make_traffic.py $TAG $OUT --traffic-only || exit 5
+for CFG in cfg3 cfg2 cfg5 cfg4; do
+  python bench.py --config $CFG --steps 6 --warmup 2 > $OUT/${TAG}_bench_$CFG.json 2> $OUT/bench_$CFG.err || exit 1
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$CFG -- python bench.py --config $CFG --steps 4 --warmup 1 --no-cpu-baseline --no-noise > $OUT/stats_$CFG.log 2>&1 || exit 2
+  cp $OUT/stats_$CFG/*/*kernel_stats.csv $OUT/${TAG}_bench_${CFG}_kernel_stats.csv
+  echo "$CFG done: $(tail -c 300 $OUT/${TAG}_bench_$CFG.json | head -c 10)"
+done
+ls $OUT
