@@ -19,7 +19,7 @@ EXPORTS = [
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
-    'nbls_developer_build', 'nbls_set_trace_from',
+    'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -103,6 +103,7 @@ def load_library(path=None):
     lib.nbls_set_window_ranges.argtypes = [vp, C.c_int32, ip, ip]
     lib.nbls_debug_screen_stamps.argtypes = [vp, dp]
     lib.nbls_debug_lts_stamps.argtypes = [vp, dp]
+    lib.nbls_debug_lts_coop_breakdown.argtypes = [vp, dp]
     for name in EXPORTS:
         if name not in ('nbls_destroy', 'nbls_last_error'):
             getattr(lib, name).restype = C.c_int
@@ -324,6 +325,11 @@ class Handle:
         out = np.zeros(8)
         self._chk(self.lib.nbls_debug_lts_stamps(self._h, _dptr(out)))
         return dict(zip(('setup_medians', 'elemental_starts', 'csteps', 'peel', 'refine', 'finish', 'nfin', 'total'), out))
+
+    def lts_coop_breakdown(self):
+        out = np.zeros(4)
+        self._chk(self.lib.nbls_debug_lts_coop_breakdown(self._h, _dptr(out)))
+        return dict(zip(('select', 'merge', 'sums', 'live_entries_total'), out))
 
     def screen_stats(self):
         out = (C.c_int64 * 4)()

@@ -473,7 +473,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
         if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (10 + WP_ / 32) * sizeof(double)))) return rc;
         if (h->opt.screen_stamps || h->opt.lts_stamps) {
-            if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * 8 * sizeof(unsigned long long)))) return rc;
+            if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * ((h->nchans + 14) / 16) * 8 * sizeof(unsigned long long)))) return rc;   // one record per screening workgroup: (unit, sliding channel, partner group)
         }
         if ((rc = ensure(h, &h->d_cand, &h->cap_cand, (size_t)batch * h->nchans * h->nchans * 32 * sizeof(int32_t)))) return rc;
     }
@@ -770,6 +770,22 @@ int nbls_debug_lts_stamps(nbls_handle* h, double* out8) {
         ++cnt;
     }
     for (int i = 0; i < 8; ++i) out8[i] /= (double)(cnt > 0 ? cnt : 1);
+    return NBLS_OK;
+}
+
+int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out4) {
+    // developer: mean over the units of the cooperative LTS kernel's C-step phase, thread 0's cycles in
+    // {selection, subset merging, sums} and the number of live entries summed over the iterations
+    if (!h || !out4) return NBLS_ERR_ARG;
+    if (!h->d_stamps || h->lts_stamp_waves <= 0) return fail(h, NBLS_ERR_STATE, "developer build with option lts_stamps needed");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> st((size_t)h->lts_stamp_waves * 8);
+    HIPCHK(h, copy_sync(h, st.data(), h->d_stamps + (size_t)h->lts_stamp_waves * 8, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = 0.0;
+    for (int64_t g = 0; g < h->lts_stamp_waves; ++g)
+        for (int i = 0; i < 4; ++i) out4[i] += (double)st[(size_t)g * 8 + i];
+    for (int i = 0; i < 4; ++i) out4[i] /= (double)h->lts_stamp_waves;
     return NBLS_OK;
 }
 

@@ -685,7 +685,7 @@ __device__ inline void fit_sums(const double* txx, const double* txy, const doub
     const unsigned int mlo = (unsigned int)mask, mhi = (unsigned int)(mask >> 32);
     auto one = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const unsigned int in = k < 32 ? ((mlo >> k) & 1u) : ((mhi >> (k - 32)) & 1u);
+        const unsigned int in = k < 32 ? ((mlo >> (k < 32 ? k : 0)) & 1u) : ((mhi >> (k >= 32 ? k - 32 : 0)) & 1u);
         const double w = (double)in;
         sxx = __builtin_fma(txx[k], w, sxx);
         sxy = __builtin_fma(txy[k], w, sxy);
@@ -1207,15 +1207,19 @@ size_t lts_coop_lds_bytes(int P, int S) {
 }
 
 // One wave: h-subset of the fit (z0, z1) over the rows (yv, c0, c1)[0..P) -> mask row `out` (PW words).
-__device__ inline void coop_select(const double* yv, const double* c0, const double* c1, int P, int h,
-                                   double z0, double z1, unsigned long long* out, int lane) {
-    const int PW = (P + 63) / 64;
-    unsigned long long key[8];
+// (PWT = ceil(P / 64) is a template parameter: every loop over the lane's keys is unrolled to exactly PWT
+//  steps — with a run-time bound the 8-step loops spent more cycles on scalar tests and branches than on the
+//  ballots: 6 000 cycles per selection at 120 pairs.)
+template <int PWT>
+__device__ inline void coop_select_t(const double* yv, const double* c0, const double* c1, int P, int h,
+                                     double z0, double z1, unsigned long long* out, int lane) {
+
+    unsigned long long key[PWT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PWT; ++i) {
         key[i] = ~0ull;                              // beyond P: larger than every candidate threshold
         const int k = lane + 64 * i;
-        if (i < PW && k < P)
+        if (k < P)
             key[i] = (unsigned long long)__double_as_longlong(fabs((yv[k] - c0[k] * z0) - c1[k] * z1));
     }
     // h-th smallest key, high word first (31 passes of 32-bit compares); the low word needs its own
@@ -1224,8 +1228,8 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
     // below the highest bit in which the smallest and the largest differ
     unsigned int hmin = ~0u, hmax = 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < PW && lane + 64 * i < P) {
+    for (int i = 0; i < PWT; ++i)
+        if (lane + 64 * i < P) {
             const unsigned int hw = (unsigned int)(key[i] >> 32);
             hmin = hw < hmin ? hw : hmin;
             hmax = hw > hmax ? hw : hmax;
@@ -1235,26 +1239,48 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
     const unsigned int hdiff = hmin ^ hmax;
     const int btop = hdiff ? 31 - __builtin_clz(hdiff) : -1;       // wave-uniform
     unsigned int Thi = btop >= 31 ? 0u : (btop < 0 ? hmin : (hmin & ~((2u << btop) - 1u)));
+    // The bisection also tracks how many keys lie below the current bucket [Thi, Thi + 2^(b+1)) and how many below
+    // its upper end: the bucket always holds the h-th smallest key, and as soon as it holds ONE key that key is the
+    // threshold — the remaining bits need no passes (about half of them at 120..496 pairs).
+    int nbelow = 0, nupto = P;
+    bool single = false;
+    unsigned int bucket_hi = 0u;                     // exclusive upper end of the bucket (high words), when single
     for (int b = btop > 30 ? 30 : btop; b >= 0; --b) {
         const unsigned int cnd = Thi | (1u << b);
         int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < PW) cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) < cnd));
-        if (cnt <= h - 1) Thi = cnd;                 // the h-th smallest high word is >= cnd
+        for (int i = 0; i < PWT; ++i)
+            cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) < cnd));
+        if (cnt <= h - 1) { Thi = cnd; nbelow = cnt; }   // the h-th smallest high word is >= cnd
+        else nupto = cnt;
+        if (nupto - nbelow == 1) { single = true; bucket_hi = Thi + (1u << b); break; }   // (no overflow: bit b of Thi's bucket base is clear or b < 31)
     }
+    unsigned int Tlo = 0u;
+    if (single) {
+        // the one key with Thi <= high word < bucket_hi IS the h-th smallest: take it whole
+#pragma unroll
+        for (int i = 0; i < PWT; ++i)
+            {
+                const unsigned int hw = (unsigned int)(key[i] >> 32);
+                const unsigned long long in = __ballot(hw >= Thi && (bucket_hi == 0u || hw < bucket_hi));
+                if (in) {
+                    const int src = __builtin_ctzll(in);
+                    Thi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(key[i] >> 32), src);
+                    Tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[i], src);
+                }
+            }
+    } else {
     int clt_hi = 0, neq = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < PW) {
+    for (int i = 0; i < PWT; ++i)
+        {
             clt_hi += __popcll(__ballot((unsigned int)(key[i] >> 32) < Thi));
             neq += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi));
         }
-    unsigned int Tlo = 0u;
     if (neq == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < PW) {
+        for (int i = 0; i < PWT; ++i)
+            {
                 const unsigned long long eq = __ballot((unsigned int)(key[i] >> 32) == Thi);
                 if (eq) Tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[i], __builtin_ctzll(eq));
             }
@@ -1264,23 +1290,23 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
             const unsigned int cnd = Tlo | (1u << b);
             int cnt = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < PW)
-                    cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi && (unsigned int)key[i] < cnd));
+            for (int i = 0; i < PWT; ++i)
+                cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi && (unsigned int)key[i] < cnd));
             if (cnt <= h2 - 1) Tlo = cnd;
         }
+    }
     }
     const unsigned long long T = ((unsigned long long)Thi << 32) | Tlo;
     int clt = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < PW) clt += __popcll(__ballot(key[i] < T));
+    for (int i = 0; i < PWT; ++i)
+        clt += __popcll(__ballot(key[i] < T));
     const int m = h - clt;                           // ties at T to take, in index order
     int prefix = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < PW) {
+    for (int i = 0; i < PWT; ++i) {
+        {
             const unsigned long long lt = __ballot(key[i] < T);
             const unsigned long long tie = __ballot(key[i] == T);
             const bool take = (key[i] == T) && (prefix + __popcll(tie & below) < m);
@@ -1288,6 +1314,20 @@ __device__ inline void coop_select(const double* yv, const double* c0, const dou
             prefix += __popcll(tie);
             if (lane == 0) out[i] = mk;
         }
+    }
+}
+
+__device__ inline void coop_select(const double* yv, const double* c0, const double* c1, int P, int h,
+                                   double z0, double z1, unsigned long long* out, int lane) {
+    switch ((P + 63) / 64) {        // wave-uniform
+        case 1: coop_select_t<1>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 2: coop_select_t<2>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 3: coop_select_t<3>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 4: coop_select_t<4>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 5: coop_select_t<5>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 6: coop_select_t<6>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        case 7: coop_select_t<7>(yv, c0, c1, P, h, z0, z1, out, lane); break;
+        default: coop_select_t<8>(yv, c0, c1, P, h, z0, z1, out, lane); break;
     }
 }
 
@@ -1320,13 +1360,26 @@ __device__ inline void coop_sums(const CoopLds& L, const double* yv, const doubl
 // C-steps in lock step for every live entry (stt == 1): entries are z0S/z1S on entry; on exit finished
 // entries (stt == 2) hold their objective in objS and their z in z0S/z1S.  maxsteps = csteps (starts) or
 // csteps2 (refinement).  Same sequence as the generic kernel: select(z) -> [fit -> select -> obj] * steps.
-__device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int maxsteps, bool dedupe, int tid, int nthr) {
+__device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int maxsteps, bool dedupe, int tid, int nthr,
+                                   unsigned long long* acc = nullptr) {
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+#ifdef NBLS_DEVELOPER
+#define COOP_ACC(i, t0) do { if (acc) acc[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define COOP_NOW() (acc ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define COOP_ACC(i, t0) do { } while (0)
+#define COOP_NOW() 0ull
+    (void)acc;
+#endif
     for (int it = 0; it <= maxsteps; ++it) {
+        unsigned long long t0 = COOP_NOW();
+        (void)t0;
         for (int s = wv; s < S; s += nwv)
             if (L.stt[s] == 1) coop_select(L.y, L.X0, L.X1, P, h, L.z0S[s], L.z1S[s], L.masks + (size_t)s * L.PWS, lane);
         __syncthreads();
-        if (dedupe && it <= 1) {
+        COOP_ACC(0, t0);
+        t0 = COOP_NOW();
+        if (dedupe && it < maxsteps) {       // (not in the last iteration: entries that finish there still carry their own z)
             // entries that landed on the SAME h-subset continue identically from here (a C-step depends
             // on the subset only): only the lowest start index of each group is carried on, the others
             // are dropped (they would end with the same (objective, z) and be discarded as duplicate
@@ -1357,9 +1410,13 @@ __device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int ma
             }
             __syncthreads();
         }
+        COOP_ACC(1, t0);
+        t0 = COOP_NOW();
         int live = 0;
+        int nlive_dbg = 0;
         for (int s = tid; s < S; s += nthr) {
             if (L.stt[s] != 1) continue;
+            ++nlive_dbg;
             double obj, n0, n1;
             coop_sums(L, L.y, L.X0, L.X1, P, L.masks + (size_t)s * L.PWS, L.z0S[s], L.z1S[s], &obj, &n0, &n1);
             const int kk = it - 1;                    // index of the C-step whose objective this is
@@ -1374,7 +1431,16 @@ __device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int ma
             L.z1S[s] = n1;
             live = 1;
         }
-        if (!__syncthreads_or(live)) break;
+        (void)nlive_dbg;
+        const int any = __syncthreads_or(live);
+        COOP_ACC(2, t0);
+#ifdef NBLS_DEVELOPER
+        {   // every thread takes part in the barrier; thread 0 (the only one with acc) records
+            const int nl = __syncthreads_count(nlive_dbg);      // live entries of this iteration
+            if (acc) acc[3] += (unsigned long long)nl;
+        }
+#endif
+        if (!any) break;
     }
 }
 
@@ -1388,6 +1454,13 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
     const int P = a.npairs, S = a.nstarts, h = a.h;
     const int64_t o = (int64_t)band * a.vector_len + w;
     const CoopLds L = coop_carve(sm, P, S);
+#ifdef NBLS_DEVELOPER      // phase stamps (same slots as the wave-per-unit kernel: nbls_debug_lts_stamps)
+    unsigned long long* stp = (a.stamps && tid == 0 && (int)blockIdx.x < a.stamp_waves) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#define COOP_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define COOP_STAMP(i) do { } while (0)
+#endif
+    COOP_STAMP(0);
 
     for (int k = tid; k < P; k += nthr) {
         const double t = (double)a.lag[o * P + k] / a.fs;
@@ -1456,6 +1529,7 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
     }
     __syncthreads();
 
+    COOP_STAMP(1);
     // ---- elemental starts: exact fit on the (up to four) points of the start, ascending index ----
     for (int s = tid; s < S; s += nthr) {
         int idx[4];
@@ -1485,8 +1559,16 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
         L.stt[s] = 1;
     }
     __syncthreads();
+    COOP_STAMP(2);
+#ifdef NBLS_DEVELOPER
+    unsigned long long* acc = stp ? a.stamps + (size_t)(a.stamp_waves + blockIdx.x) * 8 : nullptr;
+    if (acc) for (int i = 0; i < 8; ++i) acc[i] = 0;
+    coop_csteps(L, P, S, h, a.csteps, true, tid, nthr, acc);
+#else
     coop_csteps(L, P, S, h, a.csteps, true, tid, nthr);
+#endif
     __syncthreads();
+    COOP_STAMP(3);
 
     // ---- rank the finished starts by (objective, start index); NaN/inf last ----
     for (int s = tid; s < S; s += nthr) {
@@ -1532,8 +1614,10 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
         if (is_c) L.prevS[s] = 0.0;
     }
     __syncthreads();
+    COOP_STAMP(4);
     coop_csteps(L, P, S, h, a.csteps2, false, tid, nthr);
     __syncthreads();
+    COOP_STAMP(5);
     // ---- best candidate -> de-standardise ----
     double zr0 = dnan(), zr1 = dnan();
     {
@@ -1639,6 +1723,10 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
     }
     __syncthreads();
     for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = L.wsh[k];
+    COOP_STAMP(6);
+#ifdef NBLS_DEVELOPER
+    if (stp) stp[7] = (unsigned long long)nc;
+#endif
 }
 
 size_t lts_lds_bytes(int P, int S, bool absr) {
@@ -1732,7 +1820,7 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     {
         if (h->opt.lts_stamps && h->d_stamps) {
             a.stamps = h->d_stamps;
-            const int64_t cap = (int64_t)(h->cap_stamps / (8 * sizeof(unsigned long long)));
+            const int64_t cap = (int64_t)(h->cap_stamps / (8 * sizeof(unsigned long long))) / 2;   // second half: the cooperative kernel's C-step breakdown
             a.stamp_waves = (int)(nunits < cap ? nunits : cap);
             h->lts_stamp_waves = a.stamp_waves;
         }

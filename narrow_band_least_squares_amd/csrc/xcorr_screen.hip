@@ -478,25 +478,6 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         tab_b = m[tab_k];
         if (tab_row < NSL) tab_a = m[NB];
     }
-    // ---- lane roles.  The per-channel records behind the threshold are fetched HERE, before the staging loops,
-    //      so that their round trip to L2 overlaps with the staging instead of ending it ----
-    const int c = lane & 15, g = lane >> 4;
-    const int ncol = NP * S;
-    const bool colvalid = (c < ncol) && chan_ok;
-    const int cc = (c < ncol) ? c : 0;               // idle columns mirror column 0 (LDS broadcast)
-    const int jj = cc % NP;
-    const int s = cc / NP;
-    const int cis = chan_ok ? ci : 0;
-    const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);
-    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * a.qms;
-    const double* mj = a.qmeta + ((int64_t)ul * N + j) * a.qms;
-    // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
-    // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
-    const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
-                            ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
-    const double lolo = sqrt(mi[6 + WP / 32] * mj[6 + WP / 32]);           // bound of the dropped LL product
-    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
-    const float iabs6 = __double2float_ru(1.0e-6 * iabs);       // f32 recombination slack of the pruning test (rounded up)
     if (stage_on)
     for (int row0 = wv; row0 < nrowB; row0 += 2 * nwaves) {
         for (int g0 = lane; g0 < gB; g0 += 256) {
@@ -581,6 +562,23 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             cumT[(row - NSL) * (NB + 1) + k] = __double2float_ru(m[k]);
         }
     }
+    // ---- lane roles (the pair records are fetched before the staging barrier: one round trip less) ----
+    const int c = lane & 15, g = lane >> 4;
+    const int ncol = NP * S;
+    const bool colvalid = (c < ncol) && chan_ok;
+    const int cc = (c < ncol) ? c : 0;               // idle columns mirror column 0 (LDS broadcast)
+    const int jj = cc % NP;
+    const int s = cc / NP;
+    const int cis = chan_ok ? ci : 0;
+    const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);
+    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * a.qms;
+    const double* mj = a.qmeta + ((int64_t)ul * N + j) * a.qms;
+    // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
+    // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
+    const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
+                            ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
+    const double lolo = sqrt(mi[6 + WP / 32] * mj[6 + WP / 32]);           // bound of the dropped LL product
+    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
     stamp(stp, 1);
     __syncthreads();
     stamp(stp, 2);
@@ -607,6 +605,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // and the groups' K ranges shrink with p, so every SIMD gets the same matrix-core work
     const int wvu = __builtin_amdgcn_readfirstlane(half ? 3 - (wv & 3) : (wv & 3));
     // energy tables of the two channels of this lane's column (see quantize_kernel)
+    const double* cum_i = mi + 4;
+    const double* cum_j = mj + 4;
 
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
 // 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
@@ -672,16 +672,10 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
                 const int kp = (W - D0 + 31) / 32 < NB ? (W - D0 + 31) / 32 : NB;
-                float bound;
-                if (a.tab_lds) {
-                    bound = sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f;
-                } else {            // energy tables of the two channels of this lane's column, from global memory
-                    const double* cum_i = a.qmeta + ((int64_t)ul * N + cis) * a.qms + 4;
-                    const double* cum_j = a.qmeta + ((int64_t)ul * N + j) * a.qms + 4;
-                    bound = (float)(sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]) * (1.0 + 1e-6));
-                }
+                const float bound = a.tab_lds ? sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f
+                                              : (float)(sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]) * (1.0 + 1e-6));
                 const float gm = ord2f(gmaxh[jj]);
-                prunable = bound * 1.000001f + iabs6 < gm - theta;
+                prunable = bound * 1.000001f + (float)(1.0e-6 * iabs) < gm - theta;
             }
             if (__all(prunable)) continue;
         }
