@@ -201,7 +201,7 @@ def main():
                 w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_)
             if lts_:
                 res.keys = engine.time_keys(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
-                res.stdict = {}
+                res.stdict = engine.new_stdict(len(res.keys))
 
         def group_done(res, b0, b1):
             if lts_:

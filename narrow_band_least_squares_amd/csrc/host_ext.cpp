@@ -198,6 +198,7 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
             size_obj = PyLong_FromLong(nchans);
             std::vector<int32_t> dropped((size_t)P);
             std::unordered_map<std::string, PyObject*> patterns;     // mask bytes -> shared value array (owned)
+            std::unordered_map<uint64_t, PyObject*> patterns64;       // the same for up to 64 pairs: the mask IS the key
             std::string pat((size_t)MB, '\0');
             const uint8_t* last = nullptr;                            // run of equal masks: skip the lookup
             PyObject* last_arr = nullptr;
@@ -221,10 +222,16 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                             }
                         }
                         if (c) {
-                            auto it = patterns.find(pat);
-                            if (it != patterns.end()) {
-                                arr = it->second;
+                            uint64_t key64 = 0;
+                            if (MB <= 8) {
+                                memcpy(&key64, pat.data(), (size_t)MB);
+                                auto it64 = patterns64.find(key64);
+                                if (it64 != patterns64.end()) arr = it64->second;
                             } else {
+                                auto it = patterns.find(pat);
+                                if (it != patterns.end()) arr = it->second;
+                            }
+                            if (!arr) {
                                 npy_intp dims[1] = {2 * c};
                                 arr = PyArray_SimpleNew(1, dims, NPY_INT32);
                                 if (!arr) { Py_CLEAR(d); break; }
@@ -234,7 +241,7 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                                     a[c + i] = pair[2 * dropped[i] + 1] + 1;
                                 }
                                 PyArray_CLEARFLAGS((PyArrayObject*)arr, NPY_ARRAY_WRITEABLE);
-                                patterns.emplace(pat, arr);
+                                if (MB <= 8) patterns64.emplace(key64, arr); else patterns.emplace(pat, arr);
                             }
                         }
                         last = mm;
@@ -246,6 +253,7 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                 if (d && b == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
             }
             for (auto& kv : patterns) Py_DECREF(kv.second);
+            for (auto& kv : patterns64) Py_DECREF(kv.second);
             if (d && B == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
         }
     }
@@ -256,7 +264,17 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
     return d;
 }
 
+// An empty dict with room for n entries: the dictionary of a call grows to ~5*10^4 keys; without the hint it is
+// re-hashed a dozen times on the way (every resize re-inserts all entries).
+extern "C" PyObject* _PyDict_NewPresized(Py_ssize_t minused);
+PyObject* new_dict(PyObject*, PyObject* arg) {
+    const Py_ssize_t n = PyLong_AsSsize_t(arg);
+    if (n == -1 && PyErr_Occurred()) return nullptr;
+    return _PyDict_NewPresized(n > 0 ? n : 0);
+}
+
 PyMethodDef methods[] = {
+    {"new_dict", new_dict, METH_O, "new_dict(n) -> empty dict presized for n entries"},
     {"float_repr", float_repr, METH_O, "repr(float) computed by this module (self-test hook)"},
     {"time_keys", time_keys, METH_VARARGS, "time_keys(t, nwin, prefixes) -> flat list of key strings"},
     {"build_stdict", build_stdict, METH_VARARGS, "build_stdict(mask, nwin, pair_idx, nchans, keys) -> dict"},

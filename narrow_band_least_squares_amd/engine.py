@@ -146,10 +146,15 @@ class Prep:
 
 
 def prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_type=None, filter_order=None,
-            filter_ripple=None, vector_len=None, prefiltered=False):
+            filter_ripple=None, vector_len=None, prefiltered=False, common=None):
+    """``common``: the Prep of another band group of the same call — its co-array, taper ramps and FAST-LTS plan
+    do not depend on the bands and are reused instead of being recomputed per group."""
     check_elements(nchans, alpha)
     nb = len(band_edges)
-    xij, pair_idx, xpinv = planner.co_array(rij)
+    if common is not None:
+        xij, pair_idx, xpinv = common.xij, common.pair_idx, common.xpinv
+    else:
+        xij, pair_idx, xpinv = planner.co_array(rij)
     W = np.empty(nb, dtype=np.int32)
     inc = np.empty(nb, dtype=np.int32)
     nwin = np.empty(nb, dtype=np.int64)
@@ -168,14 +173,17 @@ def prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_t
     else:
         applied = []
         zero_phase = None
-        for (fmin, fmax) in band_edges:
-            sa, zp, sr = planner.design_bandpass(filter_type, fmin, fmax, filter_order, filter_ripple, fs)
+        # all bands of the group designed in one vectorised pass (bit-identical to SciPy's per-band design)
+        for sa, zp, sr in planner.design_bandpass_many(filter_type, band_edges, filter_order, filter_ripple, fs):
             applied.append(sa)
             sos_ret.append(sr)
             zero_phase = zp
         sos = planner.pad_sections(applied)
-        tl, tr = planner.taper_ramps(npts)
-    lts = planner.lts_plan(xij, alpha) if alpha < 1.0 else None
+        tl, tr = (common.tl, common.tr) if common is not None else planner.taper_ramps(npts)
+    if common is not None:
+        lts = common.lts
+    else:
+        lts = planner.lts_plan(xij, alpha) if alpha < 1.0 else None
     return Prep(nchans=nchans, npts=npts, fs=fs, nbands=nb, xij=xij, pair_idx=pair_idx, xpinv=xpinv, W=W, inc=inc,
                 nwin=nwin, vector_len=int(vector_len), sos=sos, zero_phase=zero_phase, tl=tl, tr=tr, lts=lts,
                 sos_ret=sos_ret, alpha=alpha, npairs=xij.shape[0], mask_bytes=(xij.shape[0] + 7) // 8)
@@ -259,11 +267,19 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     check_elements(nchans, alpha)
     ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin))
     ngroups = max(1, min(ngroups, nb))
-    # contiguous band groups of about equal unit counts
+    # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
+    # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
+    split = os.environ.get('NBLS_PIPELINE_SPLIT')
+    if split and groups is None and ngroups > 1:
+        shares = [max(0.0, float(x)) for x in split.split(',') if x.strip()]
+        ngroups = max(1, min(len(shares), nb))
+        shares = np.cumsum(shares[:ngroups]) / max(1e-30, float(np.sum(shares[:ngroups])))
+    else:
+        shares = np.arange(1, ngroups + 1) / float(ngroups)
     cum = np.concatenate(([0], np.cumsum(nwin)))
     cuts = [0]
     for g in range(1, ngroups):
-        b = int(np.searchsorted(cum, cum[-1] * g / ngroups))
+        b = int(np.searchsorted(cum, cum[-1] * shares[g - 1]))
         cuts.append(min(max(b, cuts[-1] + 1), nb - (ngroups - g)))
     cuts.append(nb)
     bounds = [(cuts[g], cuts[g + 1]) for g in range(ngroups)]
@@ -304,9 +320,10 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         res.t = tt
 
     launched = []
+    prep = None
     for g, (b0, b1) in enumerate(bounds):
         prep = prepare(nchans, npts, fs, rij, band_edges[b0:b1], winlens[b0:b1], winover, alpha, filter_type,
-                       filter_order, filter_ripple, vector_len, prefiltered)
+                       filter_order, filter_ripple, vector_len, prefiltered, common=prep)
         res.sos.extend(prep.sos_ret)
         h = handle if handle is not None else get_handle(device, 0 if sequential else g)
         if sequential and launched:               # one handle, one plan at a time: finish the previous round first
@@ -341,6 +358,13 @@ def _py_time_keys(t, nwin, prefixes=None):
         reps = map(repr, np.asarray(t[b, :int(nwin[b])], dtype=np.float64).tolist())
         out.extend([p + s for s in reps] if p else reps)
     return out
+
+
+def new_stdict(nkeys):
+    """An empty dictionary with room for ``nkeys`` entries (no re-hashing while a call's ~5*10^4 keys go in)."""
+    if _hostext is not None:
+        return _hostext.new_dict(int(nkeys) + 1)
+    return {}
 
 
 def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):

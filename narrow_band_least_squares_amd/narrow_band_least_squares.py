@@ -82,7 +82,7 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
             _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
         if ALPHA < 1.0 and want_keys:
             res.keys = engine.time_keys(res.t, res.nwin, key_prefixes)
-            res.stdict = {}
+            res.stdict = engine.new_stdict(len(res.keys))
 
     def group_done(res, b0, b1):
         # the dropped-element dictionary of the bands whose rows just landed, while later groups are still running

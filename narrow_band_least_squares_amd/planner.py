@@ -68,9 +68,128 @@ def _design_cached(filter_type, fmin, fmax, order, ripple, fs):
     raise ValueError('unknown FILTER_TYPE %r (expected "butter" or "cheby1")' % (filter_type,))
 
 
+def _bandpass_sos_batch(filter_type, f_lo, f_hi, N, rp, fs):
+    """SciPy's ``iirfilter(N, [lo, hi], rp, btype='band', ftype=..., fs=fs, output='sos')`` for MANY bands at
+    once: the same floating-point operations (analog prototype -> ``lp2bp_zpk`` -> ``bilinear_zpk`` ->
+    ``zpk2sos`` with 'nearest' pairing), element-wise over a (bands, poles) array instead of one Python call chain
+    per band (0.14 ms per band in SciPy — 7 ms of host time per 48-band call).  Band-pass only (every pole complex,
+    N zeros at +1 and N at -1).  -> (B, N, 6), or None if a band does not fit the assumptions (the caller then uses
+    SciPy).  tests/test_host.py compares the result bit for bit with SciPy over orders 1..8, both filter types."""
+    f_lo = np.asarray(f_lo, dtype=np.float64)
+    f_hi = np.asarray(f_hi, dtype=np.float64)
+    B = len(f_lo)
+    Wn = np.stack((f_lo, f_hi), axis=1) / (fs / 2)
+    if B == 0 or np.any(Wn <= 0) or np.any(Wn >= 1) or np.any(Wn[:, 0] >= Wn[:, 1]):
+        return None
+    m = np.arange(-N + 1, N, 2)
+    if filter_type == 'butter':
+        p0 = -np.exp(1j * np.pi * m / (2 * N))
+        k0 = 1
+    else:
+        eps = np.sqrt(10 ** (0.1 * rp) - 1.0)
+        mu = 1.0 / N * np.arcsinh(1 / eps)
+        theta = np.pi * m / (2 * N)
+        p0 = -np.sinh(mu + 1j * theta)
+        k0 = np.prod(-p0, axis=0).real
+        if N % 2 == 0:
+            k0 = k0 / np.sqrt(1 + eps * eps)
+    fs_ = 2.0
+    warped = 2 * fs_ * np.tan(np.pi * Wn / fs_)
+    bw = warped[:, 1] - warped[:, 0]
+    wo = np.sqrt(warped[:, 0] * warped[:, 1])
+    wo2 = np.array([float(x) ** 2 for x in wo])              # Python float powers, as in lp2bp_zpk
+    kbp = np.array([k0 * float(x) ** N for x in bw])
+    p_lp = (p0[None, :] * bw[:, None] / 2).astype(complex)
+    root = np.sqrt(p_lp ** 2 - wo2[:, None])
+    p_bp = np.concatenate((p_lp + root, p_lp - root), axis=1)          # (B, 2N)
+    fs2 = 2.0 * fs_
+    p_z = (fs2 + p_bp) / (fs2 - p_bp)
+    # gain: k * real(prod(fs2 - z) / prod(fs2 - p)); the N analog zeros sit at the origin
+    num = np.prod(fs2 - np.zeros(N, dtype=complex))
+    den = np.prod(fs2 - p_bp, axis=1)                                   # left-to-right along the row, as on a 1-D array
+    k_z = kbp * np.real(num / den)
+    # zpk2sos, 'nearest': one member of every conjugate pair, in _cplxreal's order (by real part, then |imag|)
+    tol = 100 * np.finfo(float).eps
+    idx = np.lexsort((np.abs(p_z.imag), p_z.real), axis=1)
+    pz = np.take_along_axis(p_z, idx, axis=1)
+    if np.any(np.abs(pz.imag) <= tol * np.abs(pz)):
+        return None                                                     # a real pole: not the band-pass structure assumed here
+    up = pz.imag > 0
+    if not np.all(up.sum(axis=1) == N):
+        return None
+    zp = pz[up].reshape(B, N)
+    zn = pz[~up].reshape(B, N)
+    if N > 1 and np.any(np.diff(zp.real, axis=1) <= tol * np.abs(zp[:, :-1])):
+        return None                                                     # equal real parts: _cplxreal re-sorts such runs, leave it to SciPy
+    pc = (zp + zn.conj()) / 2
+    # sections are filled from the last one: the pole closest to the unit circle first (argmin with removal = a
+    # stable ascending sort), each with its two nearest remaining zeros (all real: N at -1, N at +1)
+    order = np.argsort(np.abs(1 - np.abs(pc)), axis=1, kind='stable')
+    n_minus = np.full(B, N)
+    n_plus = np.full(B, N)
+    sos = np.zeros((B, N, 6))
+    sos[:, :, 0] = 1.0
+    sos[:, :, 3] = 1.0
+    rows = np.arange(B)
+    for kk in range(N):
+        si = N - 1 - kk
+        p1 = pc[rows, order[:, kk]]
+        d_minus = np.abs(-1.0 - p1)
+        d_plus = np.abs(1.0 - p1)
+        if np.any(d_minus == d_plus):
+            return None                                                 # a tie: argsort's pick is arbitrary, leave it to SciPy
+        zz = []
+        for _ in range(2):
+            take_minus = (n_minus > 0) & ((d_minus < d_plus) | (n_plus == 0))
+            zz.append(np.where(take_minus, -1.0, 1.0))
+            n_minus = n_minus - take_minus
+            n_plus = n_plus - (~take_minus)
+        z1, z2 = zz
+        pr, pi_ = p1.real, p1.imag
+        sos[:, si, 1] = (-z2) + (-z1)                                   # np.poly([z1, z2]) by convolution
+        sos[:, si, 2] = (-z1) * (-z2)
+        sos[:, si, 4] = (-pr) + (-pr)                                   # np.poly([p1, conj(p1)]).real
+        sos[:, si, 5] = pr * pr + pi_ * pi_
+    sos[:, 0, :3] *= k_z[:, None]
+    return sos
+
+
+def design_bandpass_many(filter_type, edges, order, ripple, fs):
+    """``design_bandpass`` for a list of (fmin, fmax): cached designs are reused, the others are designed in one
+    vectorised pass (``_bandpass_sos_batch``) and entered into the same cache.  -> list of (applied sos, zero_phase,
+    returned sos), exactly what ``design_bandpass`` returns band by band."""
+    out = [None] * len(edges)
+    todo = []
+    for n, (fmin, fmax) in enumerate(edges):
+        key = (filter_type, float(fmin), float(fmax), int(order), float(ripple), float(fs))
+        hit = _batch_cache.get(key)
+        if hit is not None:
+            out[n] = (hit.copy(), filter_type == 'butter', hit.copy())
+        else:
+            todo.append((n, key))
+    if todo and filter_type in ('butter', 'cheby1'):
+        fe = 0.5 * fs
+        ok = [t for t in todo if (filter_type != 'butter' or not (t[1][2] / fe - 1.0 > -1e-6))]
+        batch = _bandpass_sos_batch(filter_type, [t[1][1] for t in ok], [t[1][2] for t in ok], int(order), float(ripple), float(fs)) if ok else None
+        if batch is not None:
+            for (n, key), sos in zip(ok, batch):
+                if len(_batch_cache) > 8192:
+                    _batch_cache.clear()
+                _batch_cache[key] = sos
+                out[n] = (sos.copy(), filter_type == 'butter', sos.copy())
+    for n, (fmin, fmax) in enumerate(edges):
+        if out[n] is None:              # Nyquist high-pass case, unusual pole structure, unknown type (raises): band by band
+            out[n] = design_bandpass(filter_type, fmin, fmax, order, ripple, fs)
+    return out
+
+
+_batch_cache = {}
+
+
 def design_cache_clear():
     """Forget cached filter designs (bench.py clears them before every timed call)."""
     _design_cached.cache_clear()
+    _batch_cache.clear()
 
 
 def pad_sections(sos_list):

@@ -484,3 +484,41 @@ print('SAN_OK')
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'SAN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-4000:]
+
+
+def test_vectorised_filter_design_is_bitwise_scipy():
+    """planner._bandpass_sos_batch restates SciPy's iirfilter(..., output='sos') band-pass chain (prototype ->
+    lp2bp_zpk -> bilinear_zpk -> zpk2sos 'nearest') element-wise over many bands: every coefficient, including the
+    sign of zeros, equals SciPy's per-band result; band sets it declines (real poles, ties) go to SciPy."""
+    from scipy import signal
+    checked = 0
+    for ftype in ('butter', 'cheby1'):
+        for order in (1, 2, 3, 4, 6, 8):
+            for fs in (20.0, 40.0, 100.0, 37.3):
+                for fl in (np.logspace(np.log10(0.05), np.log10(fs * 0.49), 24), np.linspace(0.3, fs * 0.49, 17),
+                           0.05 * 2.0 ** np.arange(0, int(np.log2(fs * 0.49 / 0.05)))):
+                    sos = planner._bandpass_sos_batch(ftype, fl[:-1], fl[1:], order, 0.01, fs)
+                    if sos is None:
+                        continue
+                    for i in range(len(fl) - 1):
+                        ref = signal.iirfilter(order, [fl[i], fl[i + 1]], rp=0.01, btype='band', ftype=ftype, fs=fs, output='sos')
+                        np.testing.assert_array_equal(sos[i], ref)
+                        assert not np.any(np.signbit(sos[i]) != np.signbit(ref))
+                        checked += 1
+    assert checked > 1500
+    # the public entry: same triples as design_bandpass, cache shared, Nyquist band handed to the scalar path
+    planner.design_cache_clear()
+    edges = [(0.1, 0.2), (1.0, 3.0), (4.0, 9.0)]
+    many = planner.design_bandpass_many('butter', edges, 2, 0.01, 20.0)
+    for (lo, hi), (sa, zp, sr) in zip(edges, many):
+        a, z, r = planner.design_bandpass('butter', lo, hi, 2, 0.01, 20.0)
+        np.testing.assert_array_equal(sa, a)
+        np.testing.assert_array_equal(sr, r)
+        assert zp is z is True
+    with pytest.warns(UserWarning):
+        planner.design_bandpass_many('butter', [(1.0, 9.999995)], 2, 0.01, 20.0)    # within 1e-6 of Nyquist: obspy's high-pass fallback
+    with pytest.raises(ValueError):
+        planner.design_bandpass_many('butter', [(1.0, 10.0)], 2, 0.01, 20.0)        # at Nyquist helpers.py:128's own design raises
+    with pytest.raises(ValueError):
+        planner.design_bandpass_many('bessel', [(1.0, 2.0)], 2, 0.01, 20.0)
+    assert planner.design_bandpass_many('cheby1', edges, 2, 0.01, 20.0)[0][1] is False
