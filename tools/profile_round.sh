@@ -16,4 +16,7 @@ for CFG in cfg3 cfg2 cfg5 cfg4; do
   cp $OUT/stats_$CFG/*/*kernel_stats.csv $OUT/${TAG}_bench_${CFG}_kernel_stats.csv
   echo "$CFG done: $(tail -c 300 $OUT/${TAG}_bench_$CFG.json | head -c 10)"
 done
+bash tools/pmc_traffic.sh cfg3 1 > $OUT/${TAG}_pmc_traffic_per_pass.txt 2>&1
+bash tools/pmc_screen.sh 1 > $OUT/${TAG}_sq_counters.txt 2>&1
+python tools/call_breakdown.py 2>&1 | grep -v CAUTION > $OUT/${TAG}_call_breakdown.txt
 ls $OUT

@@ -22,8 +22,12 @@ def main():
     reps = int(pos[2]) if len(pos) > 2 else 3
     impl = int(opts.pop('impl', 0))
     nbands = int(opts.pop('bands', 0))
+    noise = int(opts.pop('noise', 0))
     c = synthetic.build_config(name, scale=scale)
     rows, fs, t0 = engine.stream_rows(c['st'])
+    if noise:          # incoherent white noise of the same shape (no common signal)
+        rng = np.random.default_rng(7)
+        rows = [rng.standard_normal(len(r)) for r in rows]
     step = 2 if c['band_type'] == '2_octave_over' else 1
     nb = nbands or c['NBANDS']
     edges = [(c['freqlist'][i], c['freqlist'][i + step]) for i in range(nb)]
