@@ -193,3 +193,24 @@ def test_raw_trace_with_a_gap_propagates_like_sosfilt(oracle):
     sub = _sub_config(d, [2, 3])
     got, exp = _compare_nbls(oracle, sub, np.logspace(-2, 1, 16))
     assert np.isfinite(got[0][:, :got[6][0]]).all()            # the other five elements still give a solution
+
+
+def test_long_windows_of_example_py_at_100_hz(oracle):
+    """example.py's adaptive WINLEN_1 = 60 s on 100 Hz data (cfg-4's rate) is W = 6000 samples — beyond round 1's
+    3840-sample cap.  With 8 elements the int8 images no longer fit LDS, the general FP64 correlator (two windows
+    in 96 KB of LDS) takes over: lags, maxima and the solution exactly the oracle's."""
+    fs, nchans, winlen = 100.0, 8, 60.0
+    rij = synthetic.array_geometry(nchans, 1.0, seed=77)
+    data = synthetic.plane_wave(rij, int(2.6 * winlen * fs), fs, 0.2, 4.0, seed=9)
+    c = dict(fs=fs, rij=rij - rij.mean(axis=1, keepdims=True))
+    st = oracle.make_stream(data, fs, starttime=17884.0729166667)
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        _compare_ltsva(oracle, c, st, winlen, 1.0)
+        assert h.timings()['xcorr_impl'] == 1            # the VALU correlator with > 64 KB of dynamic LDS
+    finally:
+        h.set_profiling(False)
+    with pytest.raises(ValueError, match='10000'):
+        from narrow_band_least_squares_amd import ltsva
+        ltsva(synthetic.make_stream(data, fs), None, None, 120.0, 0.5, 1.0, rij=c['rij'])     # W = 12000: the documented limit
