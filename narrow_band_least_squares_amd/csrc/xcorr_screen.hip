@@ -375,6 +375,9 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {
 // One workgroup = one unit x TWO sliding channels (waves 0-3 slide channel 2*cp, waves 4-7 channel
 // 2*cp+1): the partner images of all N channels are staged once for both, which halves the staging
 // traffic and the per-workgroup fixed costs per unit.
+// 8 waves: two sliding channels x 4 waves, or — when the images of all channels do not fit twice — one sliding
+// channel x 8 waves (16 elements x 3000 samples: 160 KB, one workgroup per CU; 4 waves left the CU with one wave
+// per SIMD: 17.5 -> 13.7 ms at the cfg-4 shape.  16 waves were slower again: 15.5 ms).
 __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgroups per CU: <= 128 VGPRs
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     unsigned long long* const stp = nullptr;
 #endif
     stamp(stp, 0);
-    const int half = wv >> 2;                        // which sliding channel of the pair
+    const int half = NSL == 2 ? wv >> 2 : 0;         // which sliding channel of the pair (one channel: all waves on it)
     const int ci = NSL * cp + half;
     const bool chan_ok = ci < N;                     // odd N: the last pair has one channel
     const int u = a.u0 + ul;
@@ -444,8 +447,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int gA = CSA / 8;
     const int nwaves = nthr >> 6;
     const int nrowB = 2 * nimg;
-    const int nrowA = 2 * NSL;                       // 4 or 2; nwaves / nrowA == 2
+    const int nrowA = 2 * NSL;                       // 4 or 2 rows (channel, limb), nsubA = nwaves / nrowA waves each (2 or 4)
     const int rowA = wv & (nrowA - 1), subA = wv >> (NSL == 2 ? 2 : 1);
+    const int strideA = (nwaves / nrowA) * 64;       // groups of a row taken per pass by its waves
     const int hsA = rowA >> 1, limbA = rowA & 1;
     const int chsA = NSL * cp + hsA;
     const bool stage_on = !(NBLS_ABL(2));
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     unsigned int asd[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
-        const int g = subA * 64 + lane + pa * 128;
+        const int g = subA * 64 + lane + pa * strideA;
         if (stage_on && chsA < N && g < gA) {
             if (g * 8 < WP) {
                 const uint2 lo2 = *(const uint2*)(srcA + g * 8);
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
-        const int g = subA * 64 + lane + pa * 128;
+        const int g = subA * 64 + lane + pa * strideA;
         if (stage_on && chsA < N && g < gA) {
             const unsigned int* sdw = asd[pa];
 #pragma unroll
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             }
         }
     }
-    for (int g = subA * 64 + lane + 256; stage_on && chsA < N && g < gA; g += 128) {   // long windows
+    for (int g = subA * 64 + lane + 2 * strideA; stage_on && chsA < N && g < gA; g += strideA) {   // long windows
         unsigned int sdw[4] = {0, 0, 0, 0};
         if (g * 8 < WP) {
             const uint2 lo2 = *(const uint2*)(srcA + g * 8);
@@ -603,7 +607,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int ngrp4 = (ntile + TB - 1) / TB;
     // the second sliding channel deals its groups in the opposite order: waves w and w+4 share a SIMD,
     // and the groups' K ranges shrink with p, so every SIMD gets the same matrix-core work
-    const int wvu = __builtin_amdgcn_readfirstlane(half ? 3 - (wv & 3) : (wv & 3));
+    const int nw = nwaves / NSL;                     // waves per sliding channel: 4, or 8 with one channel per workgroup
+    const int wvu = __builtin_amdgcn_readfirstlane(NSL == 2 ? (half ? 3 - (wv & 3) : (wv & 3)) : wv);
     // energy tables of the two channels of this lane's column (see quantize_kernel)
     const double* cum_i = mi + 4;
     const double* cum_j = mj + 4;
@@ -647,7 +652,6 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      |I[d]| <= sqrt(E_i[d..W) * E_j[0..W-d))  for all d >= D0.  The first round (smallest lags,
     //      where the maximum usually is) establishes the maxima; far lag blocks of coherent windows are
     //      then never computed ----
-    const int nw = 4;
     for (int rnd = 0; chan_ok; ++rnd) {
         int p;
         bool may_prune;
@@ -1196,7 +1200,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         }
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(256 * a.nsl), lds, h->stream, a);
+        // 8 waves: two sliding channels x 4, or one channel x 8
+        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vlds <= 80 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(512), vlds, h->stream, a);
