@@ -151,6 +151,23 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
 /* Copy the filtered+tapered trace of planned band `band` to host: out[nchans][npts]. */
 int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out);
 
+/* ---- time-segmented filtering (a band whose filtered trace does not fit the HBM budget) ----
+ * The trace is fed in consecutive time segments (nbls_set_trace per segment, nbls_plan for its length); the IIR state
+ * is handed from segment to segment, so the output equals the whole-trace filter (helpers.py:124-139) up to the
+ * rounding of the carried states.
+ *   nbls_filter_segment(h, reverse, state_in, state_out)
+ *       reverse = 0: ONE causal pass over the resident raw segment, forward in time, into the filtered buffer;
+ *       reverse = 1: one causal pass over the filtered buffer IN PLACE, backward in time (the second half of a
+ *       zero-phase filter: feed the forward outputs back with nbls_set_filtered, last segment first).
+ *       state_in / state_out: [nbands][nchans][2 * nsections] DF2T states entering the segment / leaving its last
+ *       whole 512-sample chunk (NULL = zero state / not wanted).  A segment that hands a state on must be a multiple
+ *       of 512 samples long (every segment but the last in time).  No taper is applied: the caller multiplies the
+ *       whole-trace taper in at global sample positions.
+ *   nbls_set_filtered(h, band, data[nchans][npts])   write one band of the filtered buffer (the forward outputs of a
+ *       segment, before the backward pass). */
+int nbls_filter_segment(nbls_handle* h, int32_t reverse, const double* state_in, double* state_out);
+int nbls_set_filtered(nbls_handle* h, int32_t band, const double* data);
+
 /* Device pointers of the result grids (for an RCCL gather straight from HBM):
  * ptrs[0..3] = vel, baz, mdccm, sigma_tau (double[nbands][vector_len]); ptrs[4] = nwin (int32).
  * The four grids are the head of the result block (see nbls_result_layout): always contiguous,

@@ -19,7 +19,8 @@ EXPORTS = [
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
-    'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown',
+    'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown', 'nbls_filter_segment',
+    'nbls_set_filtered',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -82,6 +83,8 @@ def load_library(path=None):
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
     lib.nbls_set_trace_from.argtypes = [vp, vp]
+    lib.nbls_filter_segment.argtypes = [vp, C.c_int32, dp, dp]
+    lib.nbls_set_filtered.argtypes = [vp, C.c_int32, dp]
     lib.nbls_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.nbls_set_geometry.argtypes = [vp, dp, ip, dp, C.c_int32]
     plan_args = [vp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip, ip, C.c_int32,
@@ -240,6 +243,7 @@ class Handle:
                                      len(tl), _iptr(winlen), _iptr(wininc), int(vector_len), lp,
                                      int(xcorr_impl)))
         self.nbands, self.vector_len = nb, int(vector_len)
+        self._nsec = nsec
 
     def set_option(self, key, value):
         """Per-handle implementation switch (``nbls_set_option``; identical results unless the library is the
@@ -299,6 +303,20 @@ class Handle:
         out = np.empty((self.nchans, self.npts))
         self._chk(self.lib.nbls_fetch_filtered(self._h, int(band), _dptr(out)))
         return out
+
+    def filter_segment(self, reverse=False, state_in=None, want_state=False):
+        """One causal filter pass over the resident segment continuing from ``state_in`` (nbands, nchans, 2*nsections)
+        -> the state leaving the segment (or None).  See ``nbls_filter_segment``."""
+        si = None if state_in is None else _f64(state_in)
+        so = np.empty((self.nbands, self.nchans, 2 * self._nsec)) if want_state else None
+        self._chk(self.lib.nbls_filter_segment(self._h, int(bool(reverse)), _dptr(si), _dptr(so)))
+        return so
+
+    def set_filtered(self, band, data):
+        data = _f64(data)
+        if data.shape != (self.nchans, self.npts):
+            raise ValueError('filtered band must be (nchans, npts)')
+        self._chk(self.lib.nbls_set_filtered(self._h, int(band), _dptr(data)))
 
     def device_results(self):
         ptrs = (C.c_void_p * 5)()

@@ -195,7 +195,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -589,6 +589,41 @@ int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out) {
     HIPCHK(h, hipMemcpy2DAsync(out, h->npts * sizeof(double),
                                h->d_filt + (size_t)band * h->nchans * h->npts_pad, h->npts_pad * sizeof(double),
                                h->npts * sizeof(double), h->nchans, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NBLS_OK;
+}
+
+int nbls_set_filtered(nbls_handle* h, int32_t band, const double* data) {
+    if (!h || !data) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_set_filtered: no plan");
+    if (band < 0 || band >= h->nbands) return fail(h, NBLS_ERR_ARG, "nbls_set_filtered: band out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_filt + (size_t)band * h->nchans * h->npts_pad, h->npts_pad * sizeof(double), data,
+                               h->npts * sizeof(double), h->npts * sizeof(double), h->nchans, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NBLS_OK;
+}
+
+int nbls_filter_segment(nbls_handle* h, int32_t reverse, const double* state_in, double* state_out) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_filter_segment: no plan");
+    if (h->nsections < 1) return fail(h, NBLS_ERR_ARG, "nbls_filter_segment: the plan has no filter sections");
+    if (state_out && (h->npts % NBLS_FILTER_CHUNK) != 0 && !reverse)
+        return fail(h, NBLS_ERR_ARG, "nbls_filter_segment: a segment whose end state is wanted must be a whole number of 512-sample chunks");
+    if (reverse && state_in && (h->npts % NBLS_FILTER_CHUNK) != 0)
+        return fail(h, NBLS_ERR_ARG, "nbls_filter_segment: a backward segment that continues a state must be a whole number of 512-sample chunks");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->nbands * h->nchans * 2 * h->nsections;
+    int rc;
+    if ((rc = ensure(h, &h->d_seg_state, &h->cap_seg_state, 2 * n * sizeof(double)))) return rc;
+    double* d_init = nullptr;
+    double* d_fin = state_out ? h->d_seg_state + n : nullptr;
+    if (state_in) {
+        d_init = h->d_seg_state;
+        HIPCHK(h, hipMemcpyAsync(d_init, state_in, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, nbls_launch_filter_segment(h, reverse ? 1 : 0, d_init, d_fin));
+    if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, d_fin, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NBLS_OK;
 }

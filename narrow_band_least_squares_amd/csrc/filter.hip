@@ -59,6 +59,8 @@ struct FilterArgs {
     const double* tl;
     const double* tr;
     int taper_len;
+    const double* init;    // [nseries][2S] state entering the first chunk (time-segmented filtering), else NULL = zero
+    double* fin;           // [nseries][2S] state after the last (whole) chunk, else NULL
 };
 
 // ---- states: one wave per (series, chunk) ----
@@ -214,7 +216,7 @@ __global__ void filter_carry_groups_kernel(FilterArgs a) {
     const int band = q / a.nchans;
     double s[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = 0.0;
+    for (int i = 0; i < D; ++i) s[i] = a.init ? a.init[(int64_t)q * D + i] : 0.0;
     for (int gi = 0; gi < a.ngroups; ++gi) {
         double* gin = a.gin + ((int64_t)gi * a.nseries + q) * D;
         const double* ge = a.gend + ((int64_t)gi * a.nseries + q) * D;
@@ -233,6 +235,10 @@ __global__ void filter_carry_groups_kernel(FilterArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) s[i] = sn[i];
+    }
+    if (a.fin) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) a.fin[(int64_t)q * D + i] = s[i];
     }
 }
 
@@ -411,6 +417,8 @@ hipError_t run_filter(nbls_handle* h) {
     a.tl = h->d_tl;
     a.tr = h->d_tr;
     a.taper_len = h->taper_len;
+    a.init = nullptr;
+    a.fin = nullptr;
     a.out = h->d_filt;
     a.out_stride = h->npts_pad;
     // pass 1: raw trace -> filtered buffer, forward in time
@@ -439,6 +447,50 @@ hipError_t run_filter(nbls_handle* h) {
     return run_pass<S>(h, a, fuse);
 }
 
+// One causal pass over the resident segment, continuing from a given state (time-segmented filtering of traces whose
+// filtered form does not fit HBM): reverse == 0: raw trace -> filtered buffer, forward in time;
+// reverse == 1: the filtered buffer in place, backward in time (second half of a zero-phase filter).  No taper (the
+// caller applies it at global positions).  The state leaving the last WHOLE chunk is written to d_fin, so every segment
+// but the last (forward) / but the one processed first (backward) must be a whole number of chunks long.
+template <int S>
+hipError_t run_filter_segment(nbls_handle* h, int reverse, const double* d_init, double* d_fin) {
+    FilterArgs a;
+    a.nchans = h->nchans;
+    a.nseries = h->nbands * h->nchans;
+    a.npts = h->npts;
+    a.nchunks = h->nchunks;
+    a.ngroups = (int)((h->nchunks + G - 1) / G);
+    a.sos = h->d_sos;
+    a.fw = h->d_fw;
+    a.mpow = h->d_M;
+    a.cstate = h->d_cstate;
+    a.gend = h->d_gend;
+    a.gin = h->d_gin;
+    a.tl = h->d_tl;
+    a.tr = h->d_tr;
+    a.taper_len = 0;
+    a.final_pass = 0;
+    a.cstate_next = nullptr;
+    a.init = d_init;
+    a.fin = d_fin;
+    a.out = h->d_filt;
+    a.out_stride = h->npts_pad;
+    if (!reverse) {
+        a.in = h->d_trace;
+        a.in_stride = h->npts_pad;
+        a.in_mod = h->nchans;
+        a.reverse = 0;
+        a.plen = h->npts;
+    } else {
+        a.in = h->d_filt;
+        a.in_stride = h->npts_pad;
+        a.in_mod = a.nseries;
+        a.reverse = 1;
+        a.plen = h->nchunks * C;
+    }
+    return run_pass<S>(h, a, false);
+}
+
 // nsections == 0: the trace is already filtered; copy it (and apply the taper, if any).
 __global__ void copy_taper_kernel(const double* in, double* out, int64_t stride, int64_t npts, int nchans,
                                   const double* tl, const double* tr, int taper_len) {
@@ -452,6 +504,20 @@ __global__ void copy_taper_kernel(const double* in, double* out, int64_t stride,
 }
 
 }  // namespace
+
+hipError_t nbls_launch_filter_segment(nbls_handle* h, int reverse, const double* d_init, double* d_fin) {
+    switch (h->nsections) {
+        case 1: return run_filter_segment<1>(h, reverse, d_init, d_fin);
+        case 2: return run_filter_segment<2>(h, reverse, d_init, d_fin);
+        case 3: return run_filter_segment<3>(h, reverse, d_init, d_fin);
+        case 4: return run_filter_segment<4>(h, reverse, d_init, d_fin);
+        case 5: return run_filter_segment<5>(h, reverse, d_init, d_fin);
+        case 6: return run_filter_segment<6>(h, reverse, d_init, d_fin);
+        case 7: return run_filter_segment<7>(h, reverse, d_init, d_fin);
+        case 8: return run_filter_segment<8>(h, reverse, d_init, d_fin);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 hipError_t nbls_launch_filter(nbls_handle* h) {
     if (h->nsections == 0) {

@@ -79,6 +79,8 @@ struct nbls_handle {
     double* d_gend = nullptr;      // [ngroups][B*N][D]
     double* d_gin = nullptr;       // [ngroups][B*N][D]
     size_t cap_gend = 0, cap_gin = 0;
+    double* d_seg_state = nullptr; // [2][B*N][D] initial / final state of a time segment (nbls_filter_segment)
+    size_t cap_seg_state = 0;
     double* d_tl = nullptr;        // [taper_len]
     double* d_tr = nullptr;        // [taper_len]
     int32_t* d_W = nullptr;        // [B]
@@ -150,6 +152,7 @@ struct nbls_handle {
 
 // Kernel launchers (each returns hipError_t of the launch).
 hipError_t nbls_launch_filter(nbls_handle* h);
+hipError_t nbls_launch_filter_segment(nbls_handle* h, int reverse, const double* d_init, double* d_fin);
 hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);

@@ -129,11 +129,111 @@ class BandBatch:
         return self._weights
 
 
+def _filtered_budget_bytes():
+    return float(os.environ.get('NBLS_MAX_FILTERED_GB', '160')) * 2.0 ** 30
+
+
 def max_bands_per_pass(nchans, npts):
     """Bands whose filtered traces fit the HBM budget of one pass (NBLS_MAX_FILTERED_GB, default 160 of
-    the 288 GB): each band keeps an (N, npts) float64 copy resident for the correlation stage."""
-    budget = float(os.environ.get('NBLS_MAX_FILTERED_GB', '160')) * 2.0 ** 30
-    return max(1, int(budget // (8.0 * nchans * (npts + 64))))
+    the 288 GB): each band keeps an (N, npts) float64 copy resident for the correlation stage.  0: not even
+    one band fits -> ``process`` switches to the time-segmented path."""
+    return int(_filtered_budget_bytes() // (8.0 * nchans * (npts + 64)))
+
+
+def filter_band_segmented(h, rows, fs, sos_apply, zero_phase, seg_len):
+    """Band-pass ONE band of a trace that is too long for the HBM budget: the trace goes through the GPU in
+    consecutive time segments of ``seg_len`` samples (a multiple of the 512-sample scan chunk) and the IIR state
+    is handed from segment to segment (``nbls_filter_segment``), forward in time and — zero-phase — backward in
+    time over the forward outputs.  Equals the whole-trace filter (helpers.py:124-139) up to the rounding of the
+    carried states.  -> (N, npts) filtered, UNTAPERED traces on the host."""
+    nchans, npts = len(rows), len(rows[0])
+    chunk = 512
+    seg = max(chunk, int(seg_len) // chunk * chunk)
+    bounds = [(a, min(a + seg, npts)) for a in range(0, npts, seg)]
+    y = np.empty((nchans, npts))
+    sos3 = np.ascontiguousarray(sos_apply, dtype=np.float64)[None, :, :]
+
+    def plan_for(n):                # filter-only plan of an n-sample segment (one dummy window, no geometry needed)
+        h.plan(sos3, zero_phase, None, None, [2], [max(1, n)], 1)
+
+    state = None
+    for (a, b) in bounds:
+        h.set_trace_rows([r[a:b] for r in rows], fs)
+        plan_for(b - a)
+        state = h.filter_segment(False, state_in=state, want_state=(b < npts))
+        y[:, a:b] = h.fetch_filtered(0)
+    if zero_phase:
+        state = None
+        for (a, b) in reversed(bounds):
+            seg_y = np.ascontiguousarray(y[:, a:b])
+            h.set_trace(seg_y, fs)                          # (sets the segment length; the backward pass reads the filtered buffer)
+            plan_for(b - a)
+            h.set_filtered(0, seg_y)
+            state = h.filter_segment(True, state_in=state, want_state=(a > 0))
+            y[:, a:b] = h.fetch_filtered(0)
+    return y
+
+
+def process_segmented(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
+                      filter_ripple, vector_len, device=None, xcorr_impl=0, want_lag=False, want_cmax=False, want_z=False,
+                      host_overlap=None, group_done=None):
+    """The hot path when not even ONE band's filtered trace fits the HBM budget: band by band,
+    (1) the band is filtered in time segments with IIR state hand-off (``filter_band_segmented``) and tapered at
+    global positions, (2) its windows go through the correlation + solve kernels in slices of consecutive windows
+    (the ``ltsva`` entry of the device pass).  Same rows as the in-core pass up to the rounding of the carried filter
+    states; HBM holds one segment / one window slice at a time."""
+    rows = [np.ascontiguousarray(r, dtype=np.float64) for r in data]
+    nchans, npts = len(rows), len(rows[0])
+    nb = len(band_edges)
+    h = get_handle(device)
+    budget = _filtered_budget_bytes()
+    seg_len = max(512, int(budget // (16.0 * nchans)))               # raw + filtered copy of a segment
+    W, inc, nwin = [np.empty(nb, dtype=t) for t in (np.int32, np.int32, np.int64)]
+    for b in range(nb):
+        W[b], inc[b], nwin[b] = planner.window_plan(npts, fs, winlens[b], winover)
+    xij, pair_idx, _ = planner.co_array(rij)
+    P = xij.shape[0]
+    MB = (P + 7) // 8
+    grids = np.zeros((4, nb, vector_len))
+    mask = np.zeros((nb, vector_len, MB), dtype=np.uint8)
+    lag = np.zeros((nb, vector_len, P), dtype=np.int32) if want_lag else None
+    cmax = np.zeros((nb, vector_len, P)) if want_cmax else None
+    z = np.zeros((nb, vector_len, 2)) if want_z else None
+    tt = np.zeros((nb, vector_len))
+    for b in range(nb):
+        tt[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
+    designs = planner.design_bandpass_many(filter_type, band_edges, filter_order, filter_ripple, fs)
+    res = BandBatch(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], nwin=nwin.astype(int), t=tt,
+                    mask=mask, lag=lag, cmax=cmax, z=z, sos=[d[2] for d in designs], W=W, inc=inc, pair_idx=pair_idx,
+                    xij=xij, nchans=nchans, alpha=alpha, handle=h, lts=alpha < 1.0, fs=fs)
+    if host_overlap is not None:
+        host_overlap(res)
+    tl, tr = planner.taper_ramps(npts)
+    for b in range(nb):
+        sos_apply, zero_phase, _ = designs[b]
+        y = filter_band_segmented(h, rows, fs, sos_apply, zero_phase, seg_len)
+        if len(tl):
+            y[:, :len(tl)] *= tl
+            y[:, npts - len(tr):] *= tr
+        # windows in slices of consecutive windows: slice [w0, w1) needs samples [w0*inc, (w1-1)*inc + W + 1)
+        Wb, ib, nw = int(W[b]), int(inc[b]), int(nwin[b])
+        per_slice = max(1, int((budget // (16.0 * nchans) - Wb - 1) // ib))
+        for w0 in range(0, nw, per_slice):
+            w1 = min(nw, w0 + per_slice)
+            s0 = w0 * ib
+            L = min(npts - s0, (w1 - w0 - 1) * ib + Wb + 1)
+            part = process(np.ascontiguousarray(y[:, s0:s0 + L]), fs, 0.0, rij, [(None, None)], [winlens[b]], winover, alpha,
+                           prefiltered=True, handle=h, xcorr_impl=xcorr_impl, want_lag=want_lag, want_cmax=want_cmax,
+                           want_z=want_z, vector_len=w1 - w0)
+            assert int(part.nwin[0]) == w1 - w0
+            grids[:, b, w0:w1] = np.stack((part.vel[0], part.baz[0], part.mdccm[0], part.sigma_tau[0]))
+            mask[b, w0:w1] = part.mask[0]
+            for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
+                if arr is not None:
+                    arr[b, w0:w1] = getattr(part, name)[0]
+        if group_done is not None:
+            group_done(res, b, b + 1)
+    return res
 
 
 class Prep:
@@ -265,6 +365,11 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         raise ValueError('could not broadcast %d windows into result rows of length %d '
                          '(vector_len too small for this band)' % (int(nwin.max()), vector_len))
     check_elements(nchans, alpha)
+    if cap < 1 and not prefiltered:            # not even one band's filtered trace fits the HBM budget
+        return process_segmented(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
+                                 filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
+                                 group_done)
+    cap = max(1, cap)
     ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin))
     ngroups = max(1, min(ngroups, nb))
     # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first

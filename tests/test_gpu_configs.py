@@ -214,3 +214,46 @@ def test_long_windows_of_example_py_at_100_hz(oracle):
     with pytest.raises(ValueError, match='10000'):
         from narrow_band_least_squares_amd import ltsva
         ltsva(synthetic.make_stream(data, fs), None, None, 120.0, 0.5, 1.0, rij=c['rij'])     # W = 12000: the documented limit
+
+
+@pytest.mark.parametrize('ftype,alpha', [('butter', 1.0), ('cheby1', 0.5)])
+def test_time_segmented_path_when_one_band_exceeds_the_hbm_budget(oracle, monkeypatch, ftype, alpha):
+    """with a filtered-trace budget smaller than ONE band the call runs band by band, the trace goes
+    through the filter in time segments with the IIR state handed from segment to segment (forward, and backward
+    for the zero-phase Butterworth), the windows in slices.  Same tuple as the in-core call (lags and dropped
+    elements exactly, values to the rounding of the carried filter states) and as the oracle."""
+    c = _cfg('cfg2', 0.15)                      # 6 elements, 10 800 samples
+    c['alpha'], c['ftype'] = alpha, ftype
+    sub = _sub_config(c, [10, 11, 12])
+    fr = np.logspace(-2, 1, 32)
+    w = np.zeros(32)
+    args = (sub['WINLEN_list'], 0.5, alpha, c['st'], None, None, 3, w, w, sub['freqlist'], c['band_type'], fr, ftype, 2, 0.01)
+    incore = narrow_band_least_squares(*args, rij=c['rij'])
+    band_bytes = 8.0 * 6 * (c['npts'] + 64)
+    monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr(0.45 * band_bytes / 2.0 ** 30))
+    assert engine.max_bands_per_pass(6, c['npts']) == 0
+    calls = {'n': 0}
+    real = engine.filter_band_segmented
+
+    def counting(h, rows, fs, sos, zp, seg_len):
+        calls['n'] += 1
+        assert seg_len < c['npts'] / 2 and seg_len % 1 == 0           # several segments per band
+        return real(h, rows, fs, sos, zp, seg_len)
+    monkeypatch.setattr(engine, 'filter_band_segmented', counting)
+    seg = narrow_band_least_squares(*args, rij=c['rij'])
+    assert calls['n'] == 3
+    assert seg[6] == incore[6]
+    for i in (0, 1, 2):
+        np.testing.assert_allclose(seg[i], incore[i], rtol=1e-9, atol=0)
+    np.testing.assert_array_equal(seg[3], incore[3])
+    np.testing.assert_allclose(seg[5], incore[5], rtol=1e-7, atol=1e-12)
+    np.testing.assert_array_equal(seg[7], incore[7])
+    np.testing.assert_array_equal(seg[8], incore[8])
+    if alpha < 1.0:
+        assert list(seg[4].keys()) == list(incore[4].keys())
+        for k in incore[4]:
+            np.testing.assert_array_equal(seg[4][k], incore[4][k])
+    # and against the oracle, through the same helper as every other whole-call test
+    d = dict(sub)
+    d['alpha'], d['ftype'] = alpha, ftype
+    _compare_nbls(oracle, d, fr)
