@@ -181,12 +181,27 @@ def txtfile():
     print('txtfile', len(text), 'bytes;', 'read back', arrs['vel'].shape, ncl.tolist())
 
 
+def filter_golden():
+    """Output of the REFERENCE's own filter_data (helpers.py:108-141), 'cheby1' branch — SciPy iirfilter + causal
+    sosfilt per trace + the whole-trace 1 % taper (the taper is the stand-in stream's, obspy recipe [R]) — on a small
+    synthetic stream: pins the product's filter kernel to reference code directly."""
+    data, _ = synth(5, 7000, 20.0, 0.2, 4.0, seed=21)
+    st = RefStream(o.make_stream(data, 20.0, starttime=17884.0729166667))
+    stf, fs, sos = ref_helpers.filter_data(st, 'cheby1', 0.4, 2.5, 3, 0.05)
+    out = np.array([tr.data for tr in stf])
+    assert not np.shares_memory(out, data) and np.array_equal(np.array([tr.data for tr in st]), data)   # input untouched
+    np.savez_compressed(os.path.join(HERE, 'filter_cheby1_ref.npz'), data=data, fs=fs, sos=sos, filtered=out,
+                        fmin=0.4, fmax=2.5, order=3, ripple=0.05)
+    print('filter_cheby1_ref', out.shape, sos.shape)
+
+
 def extra():
     """Fixtures added in round 2 (same interpreter as `loops`): more than 99 bands — the reference's
     str(band).zfill(2) prefix becomes three characters, '100_', '101_' (narrow_band_least_squares.py:120) —
     and the text-file fixtures."""
     band_loop('loop_lts_101bands', 5, 1600, 20.0, 0.5, 5.0, 101, 'linear', 'butter', 30, 0.5, bad=4)
     txtfile()
+    filter_golden()
 
 
 if __name__ == '__main__':
@@ -197,6 +212,8 @@ if __name__ == '__main__':
         planners()
     if 'extra' in what:
         extra()
+    if 'filter' in what:
+        filter_golden()
     if 'loops' not in what:
         sys.exit(0)
     band_loop('loop_ols_cheby1_adaptive', 8, 24001, 20.0, 0.1, 5.0, 8, 'log', 'cheby1', 'adaptive', 1.0)

@@ -257,3 +257,18 @@ def test_time_segmented_path_when_one_band_exceeds_the_hbm_budget(oracle, monkey
     d = dict(sub)
     d['alpha'], d['ftype'] = alpha, ftype
     _compare_nbls(oracle, d, fr)
+
+
+def test_filter_data_against_the_references_own_output():
+    """tests/golden/filter_cheby1_ref.npz holds what the REFERENCE's filter_data (helpers.py:108-141, cheby1 branch)
+    returned for a small stream: same SOS bit for bit, filtered traces to 1e-11 of the trace scale."""
+    import os
+    from narrow_band_least_squares_amd import filter_data
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_cheby1_ref.npz'), allow_pickle=False)
+    st = synthetic.make_stream(g['data'], float(g['fs']))
+    stf, fs, sos = filter_data(st, 'cheby1', float(g['fmin']), float(g['fmax']), int(g['order']), float(g['ripple']))
+    assert fs == float(g['fs'])
+    np.testing.assert_array_equal(sos, g['sos'])
+    out = np.array([tr.data for tr in stf])
+    assert np.max(np.abs(out - g['filtered'])) <= 1e-11 * np.max(np.abs(g['filtered']))
+    np.testing.assert_array_equal(np.array([tr.data for tr in st]), g['data'])         # the input stream is not modified

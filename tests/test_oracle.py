@@ -212,3 +212,15 @@ def test_oracle_band_loop_equals_reference_loop(oracle, name, capsys):
         assert set(out[4].keys()) == set(sd.keys())
         for k in sd:
             np.testing.assert_array_equal(out[4][k], sd[k])
+
+
+def test_oracle_filter_matches_the_references_own_filter_data(oracle):
+    """tests/golden/filter_cheby1_ref.npz = output of the REFERENCE's filter_data (helpers.py:108-141, cheby1 branch:
+    SciPy design + causal sosfilt per trace + 1 % taper) run in this container (make_goldens.py filter): the oracle's
+    restatement reproduces it exactly."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_cheby1_ref.npz'), allow_pickle=False)
+    st = oracle.make_stream(g['data'], float(g['fs']))
+    stf, fs, sos = oracle.filter_data(st, 'cheby1', float(g['fmin']), float(g['fmax']), int(g['order']), float(g['ripple']))
+    np.testing.assert_array_equal(sos, g['sos'])
+    np.testing.assert_array_equal(np.array([tr.data for tr in stf]), g['filtered'])
