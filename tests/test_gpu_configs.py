@@ -272,3 +272,27 @@ def test_filter_data_against_the_references_own_output():
     out = np.array([tr.data for tr in stf])
     assert np.max(np.abs(out - g['filtered'])) <= 1e-11 * np.max(np.abs(g['filtered']))
     np.testing.assert_array_equal(np.array([tr.data for tr in st]), g['data'])         # the input stream is not modified
+
+
+def test_result_block_stays_contiguous_across_plans():
+    """A smaller plan after a bigger one keeps the allocation but must move the grid views: vel | baz | mdccm |
+    sigma_tau are always back to back (one D2H copy / one RCCL block), and the values are those of a fresh handle."""
+    c = _cfg('cfg1', 0.3)
+    fr = np.logspace(-2, 1, 16)
+    w = np.zeros(16)
+
+    def call(nb):
+        return narrow_band_least_squares(c['WINLEN_list'][:nb], 0.5, 1.0, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1],
+                                         c['band_type'], fr, 'butter', 2, 0.01, rij=c['rij'])
+    big = call(10)
+    h = engine.get_handle()
+    ptrs, nbytes = h.device_results()
+    assert all(ptrs[i + 1] - ptrs[i] == nbytes for i in range(3))
+    small = call(3)
+    ptrs, nbytes = h.device_results()
+    assert nbytes == 3 * small[0].shape[1] * 8 and all(ptrs[i + 1] - ptrs[i] == nbytes for i in range(3))
+    for i in (0, 1, 2, 5):
+        np.testing.assert_array_equal(small[i], big[i][:3])
+    again = call(10)
+    for i in (0, 1, 2, 5):
+        np.testing.assert_array_equal(again[i], big[i])
