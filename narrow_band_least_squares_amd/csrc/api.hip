@@ -62,9 +62,11 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
         HIPCHK(h, hipMalloc((void**)p, need));
         cap = need;
     }
-    // queued on the handle's stream; nbls_plan / nbls_set_geometry wait for the stream before they return
-    // (StreamGuard), i.e. before the host buffers go away
-    if (n) HIPCHK(h, hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    // queued on the handle's UPLOAD stream (highest priority: a plan made while other handles' passes fill the GPU
+    // must not wait behind them — on a low-priority compute stream the ~15 small copies of a plan took 5 ms instead
+    // of 0.3); nbls_plan / nbls_set_geometry wait for that stream before they return (StreamGuard), i.e. before the
+    // host buffers go away and before any kernel that reads the tables can be launched
+    if (n) HIPCHK(h, hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->up));
     return 0;
 }
 
@@ -72,12 +74,12 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
 // double: one step is s' = A s + g x.  Returns, for a chunk of C samples and carry groups of G chunks,
 //   fw[t][d]    = (A^(C-1-t) g)[d]         zero-state end state  e = sum_t fw[t] x_t
 //   mpow[j]     = (A^C)^j, j = 0..G        chunk / group transitions
-// Waits for the handle's stream when the enclosing API call returns, on every exit path: host tables that
+// Waits for the handle's upload stream when the enclosing API call returns, on every exit path: host tables that
 // alloc_copy queued must have been read by then.
 struct StreamGuard {
     nbls_handle* h;
     explicit StreamGuard(nbls_handle* hh) : h(hh) {}
-    ~StreamGuard() { (void)hipStreamSynchronize(h->stream); }
+    ~StreamGuard() { (void)hipStreamSynchronize(h->up); }
 };
 
 void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
@@ -182,6 +184,14 @@ int nbls_create(int device_id, nbls_handle** out) {
         return fail(nullptr, NBLS_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
     }
     (void)hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+        if (hipStreamCreateWithPriority(&h->up, hipStreamNonBlocking, greatest) != hipSuccess) {
+            h->up = h->stream;             // no priorities on this device: uploads share the compute stream
+            (void)hipGetLastError();
+        }
+    }
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     *out = h;
     return NBLS_OK;
@@ -200,6 +210,7 @@ void nbls_destroy(nbls_handle* h) {
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
+    if (h->up && h->up != h->stream) (void)hipStreamDestroy(h->up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -677,6 +688,30 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"lts_pad_kb", &nbls_options::lts_pad_kb, true},
         {"plan_timing", &nbls_options::plan_timing, true},
     };
+    if (strcmp(key, "stream_priority") == 0) {
+        // 0 normal, > 0 lower, < 0 higher (clamped to what the device offers).  Several handles of one GPU running
+        // passes side by side (the band groups of a pipelined call): the pass whose results the host wants first
+        // gets its workgroups dispatched first.  The handle must be idle; results do not depend on it.
+        HIPCHK(h, hipSetDevice(h->device));
+        int least = 0, greatest = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));       // numerically: greatest <= least
+        int prio = (int)value;
+        if (prio < greatest) prio = greatest;
+        if (prio > least) prio = least;
+        if (prio == h->stream_priority) return NBLS_OK;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+        hipStream_t s1 = nullptr, s2 = nullptr;
+        HIPCHK(h, hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, prio));
+        if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio) != hipSuccess) s2 = nullptr;
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        if (h->up == h->stream) h->up = s1;
+        (void)hipStreamDestroy(h->stream);
+        h->stream = s1;
+        h->stream2 = s2;
+        h->stream_priority = prio;
+        return NBLS_OK;
+    }
     for (const Key& k : keys) {
         if (strcmp(k.name, key) != 0) continue;
 #ifndef NBLS_DEVELOPER

@@ -46,6 +46,8 @@ struct nbls_handle {
     nbls_options opt;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
+    hipStream_t up = nullptr;          // plan-time table uploads (highest priority, see alloc_copy)
+    int stream_priority = 0;           // nbls_set_option("stream_priority")
     std::vector<hipEvent_t> pev;    // pipeline hand-off events
     bool fuse_solve = false;        // set by nbls_execute_stages when correlation + solve run pipelined
     bool solve_done = false;

@@ -1,0 +1,52 @@
+"""Developer: timeline (ms from the start of the call) of the host-side phases of one whole cfg-3 call."""
+import contextlib
+import functools
+import io
+import sys
+import time
+
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from scipy import signal
+from narrow_band_least_squares_amd import narrow_band_least_squares, synthetic, engine, planner, _hip
+
+events = []
+T0 = [0.0]
+
+
+def wrap(obj, name, label=None):
+    f = getattr(obj, name)
+    label = label or name
+
+    @functools.wraps(f)
+    def g(*a, **k):
+        t = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            events.append((label, (t - T0[0]) * 1e3, (time.perf_counter() - T0[0]) * 1e3))
+    setattr(obj, name, g)
+
+
+for n in ('prepare', 'launch', 'time_keys', 'stdict_from_mask', 'upload_trace'):
+    wrap(engine, n)
+for n in ('plan', 'execute', 'fetch_packed', 'set_trace_from'):
+    wrap(_hip.Handle, n, 'handle.' + n)
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+c = synthetic.build_config(cfg, 1.0)
+fr = np.logspace(-2, np.log10(c['fs'] / 2), 1000)
+w = np.zeros(1000)
+args = (c['WINLEN_list'], c['overlap'], c['alpha'], c['st'], None, None, c['NBANDS'], w, w, c['freqlist'],
+        c['band_type'], fr, c['ftype'], c['order'], c['ripple'])
+for rep in range(6):
+    planner.design_cache_clear()
+    events.clear()
+    T0[0] = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = narrow_band_least_squares(*args, rij=c['rij'])
+    total = (time.perf_counter() - T0[0]) * 1e3
+    del out
+print('whole call %.2f ms' % total)
+for label, a, b in sorted(events, key=lambda e: e[1]):
+    print('  %6.2f .. %6.2f  (%5.2f)  %s' % (a, b, b - a, label))
