@@ -192,6 +192,7 @@ int nbls_create(int device_id, nbls_handle** out) {
             (void)hipGetLastError();
         }
     }
+    if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) h->num_cus = 0;
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     *out = h;
     return NBLS_OK;
@@ -438,7 +439,8 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
 
     const auto tp2 = std::chrono::steady_clock::now();
     const size_t nseries = (size_t)nbands * h->nchans;
-    if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double)))) return rc;
+    // + 64 bytes: the verifier's 16-byte copies of a window that starts on an odd sample read one sample past its end
+    if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double) + 64))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate2, &h->cap_cstate2, nseries * h->nchunks * D * sizeof(double)))) return rc;
     const size_t ngroups = (size_t)((h->nchunks + NBLS_FILTER_GROUP - 1) / NBLS_FILTER_GROUP);
@@ -674,6 +676,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"lts_generic_h", &nbls_options::lts_generic_h, false},
         {"lts_coop_threads", &nbls_options::lts_coop_threads, false},
         {"verify_global", &nbls_options::verify_global, false},
+        {"verify_block", &nbls_options::verify_block, false},
         {"quantize_slab", &nbls_options::quantize_slab, false},
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},

@@ -25,6 +25,7 @@ struct nbls_options {
     int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
     int lts_coop_threads = 0;  // > 0: workgroup size of the cooperative LTS kernel
     int verify_global = 0;     // 1: verify candidates from global memory instead of LDS
+    int verify_block = 0;      // 1: block-per-unit LDS verifier instead of the persistent double-buffered one
     int quantize_slab = 0;     // 1: the LDS-slab quantize kernel for every window length
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
@@ -46,6 +47,7 @@ struct nbls_handle {
     nbls_options opt;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
+    int num_cus = 0;                   // compute units of the device (persistent grids)
     hipStream_t up = nullptr;          // plan-time table uploads (highest priority, see alloc_copy)
     int stream_priority = 0;           // nbls_set_option("stream_priority")
     std::vector<hipEvent_t> pev;    // pipeline hand-off events

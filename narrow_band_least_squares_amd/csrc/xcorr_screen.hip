@@ -990,6 +990,137 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     }
 }
 
+// Persistent, double-buffered form of verify_lds_kernel (arrays of up to 8 elements whose windows fit LDS twice): ONE
+// 16-wave workgroup per CU walks through the units of its XCD's range (see xcd_item).  While the waves evaluate the
+// candidates of unit k from one LDS buffer, the windows of unit k+1 stream into the other one by LDS-DMA
+// (global_load_lds_dwordx4: no registers, no ds_write) and its candidate records into registers; the (band, window)
+// of unit k+3 is fetched at the top of the step, BEFORE the copies are queued — vector loads return in order, so a
+// wait for anything queued after the copies would wait for the copies too (the first version of this kernel fetched
+// them afterwards and ran no faster than the block-per-unit form) — and the per-band window length / hop come from
+// LDS.  The block-per-unit form loads, waits, computes, exits, and its two resident workgroups run in lockstep:
+// developer ablations at cfg-3 gave staging 0.85 ms + candidates 1.17 ms + fixed 0.38 ms = the kernel's 2.34 ms,
+// i.e. no overlap at all.  Same arithmetic in the same order: identical results.
+// LDS: [2][N][wp] doubles (wp even, >= longest window + 2), the zero slot, W[nbands], inc[nbands].  A window that
+// starts on an odd sample is copied from one sample earlier (16-byte granules) and read at row + 1.
+struct VMeta { int ul, band, w; };
+
+// `vz` is a VGPR holding 0 that the compiler cannot see through: with a visibly wave-uniform address it moves the
+// loaded values to SGPRs at once (v_readfirstlane right behind the load = a wait for the load on the spot); this way
+// they stay in flight until vmeta_uniform() is applied, a step or two later.
+__device__ inline VMeta vmeta_load(const QArgs& a, int xcd, int share, int slot, int vz) {
+    VMeta m;
+    const int ul = xcd * share + slot;
+    m.ul = (slot < share && ul < a.nu) ? ul : -1;
+    // unconditional loads from a clamped index: nothing consumes the values in the step that issues them (a select
+    // on the loaded value would make the wave wait for it on the spot)
+    const int idx = a.u0 + (m.ul >= 0 ? m.ul : a.nu - 1) + vz;
+    m.band = a.unit_band[idx];
+    m.w = a.unit_win[idx];
+    return m;
+}
+__device__ inline VMeta vmeta_uniform(const VMeta& m) {
+    VMeta r;
+    r.ul = m.ul;
+    r.band = __builtin_amdgcn_readfirstlane(m.band);
+    r.w = __builtin_amdgcn_readfirstlane(m.w);
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void verify_dma_kernel(QArgs a, int wp, int nbands) {
+    extern __shared__ double vsm[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int P = a.npairs, N = a.nchans;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int share = (a.nu + 7) >> 3;
+    const size_t bufd = (size_t)N * wp;
+    double* const zero = vsm + 2 * bufd;
+    int* const Wl = (int*)(zero + 1);
+    int* const incl = Wl + nbands;
+    if (tid == 0) *zero = 0.0;
+    for (int b = tid; b < nbands; b += 1024) { Wl[b] = a.Wb[b]; incl[b] = a.incb[b]; }
+    // this wave's pairs (the same for every unit)
+    int pci[2], pcj[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = wv + 16 * q;
+        pci[q] = k < P ? a.pair[2 * k] : 0;
+        pcj[q] = k < P ? a.pair[2 * k + 1] : 0;
+    }
+    int slot = blockIdx.x >> 3;
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    VMeta mc = vmeta_uniform(vmeta_load(a, xcd, share, slot, vz));                 // unit k: evaluated in this step
+    VMeta mn = vmeta_uniform(vmeta_load(a, xcd, share, slot + nslot, vz));         // unit k+1: copied in during this step
+    VMeta mf = vmeta_load(a, xcd, share, slot + 2 * nslot, vz);                    // unit k+2 (values still in flight)
+    int recs_n[2] = {0, 0}, recs_c[2];
+    double ss_n = 0.0, ss_c;
+    __syncthreads();                                            // the W / inc tables
+
+// queue the copy of unit M's windows into buffer B, and the loads of its candidate records / norms
+#define VERIFY_QUEUE(M, B)                                                                                   \
+    if ((M).ul >= 0) {                                                                                       \
+        const int W_ = Wl[(M).band];                                                                         \
+        const double* src_ = a.filt + (int64_t)(M).band * N * a.npts_pad + (int64_t)(M).w * incl[(M).band]; \
+        const int off_ = (int)((((uintptr_t)src_) >> 3) & 1);   /* npts_pad is even: the same for every channel */ \
+        const int wt_ = W_ + off_;                                                                           \
+        const int npc_ = (wt_ + 127) >> 7;                       /* 1 KiB pieces per row */                  \
+        for (int q_ = wv; q_ < N * npc_; q_ += 16) {                                                         \
+            const int row_ = q_ / npc_, p_ = q_ - row_ * npc_;                                               \
+            const int n_ = 128 * p_ + 2 * lane;                                                              \
+            double* dst_ = vsm + (size_t)(B) * bufd + (size_t)row_ * wp + 128 * p_;                          \
+            if (n_ < wt_)                                                                                    \
+                __builtin_amdgcn_global_load_lds((gptr_t)(src_ - off_ + (int64_t)row_ * a.npts_pad + n_), (lptr_t)dst_, 16, 0, 0); \
+        }                                                                                                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                   \
+            recs_n[q_] = 0;                                                                                  \
+            if (wv + 16 * q_ < P) {                                                                          \
+                const int32_t* l1 = a.cand + (((int64_t)(M).ul * N + pci[q_]) * N + pcj[q_]) * CSTRIDE;      \
+                const int32_t* l2 = a.cand + (((int64_t)(M).ul * N + pcj[q_]) * N + pci[q_]) * CSTRIDE;      \
+                recs_n[q_] = lane < 32 ? l1[lane] : l2[lane - 32];                                           \
+            }                                                                                                \
+        }                                                                                                    \
+        ss_n = lane < N ? a.qmeta[((int64_t)(M).ul * N + lane) * a.qms] : 0.0;                               \
+    }
+
+    int cur = 0;
+    VERIFY_QUEUE(mc, 0)
+    __syncthreads();                                        // (waits for the copies as well: vmcnt(0))
+    while (mc.ul >= 0) {                                    // workgroup-uniform
+        slot += nslot;
+        const VMeta mg = vmeta_load(a, xcd, share, slot + 2 * nslot, vz);  // unit k+3: needed two steps from now
+#pragma unroll
+        for (int q = 0; q < 2; ++q) recs_c[q] = recs_n[q];
+        ss_c = ss_n;
+        VERIFY_QUEUE(mn, cur ^ 1)
+        const int W = Wl[mc.band];
+        const double* src = a.filt + (int64_t)mc.band * N * a.npts_pad + (int64_t)mc.w * incl[mc.band];
+        const double* buf = vsm + (size_t)cur * bufd + (int)((((uintptr_t)src) >> 3) & 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = wv + 16 * q;
+            if (k >= P) break;
+            const int ci = pci[q], cj = pcj[q];
+            const double ssa = readlane_f64(ss_c, ci), ssb = readlane_f64(ss_c, cj);
+            double best;
+            int bestk;
+            verify_pair(buf + (size_t)ci * wp, buf + (size_t)cj * wp, zero, W, recs_c[q], ssa, ssb, lane, &best, &bestk);
+            if (lane == 0) {
+                const int64_t o = ((int64_t)mc.band * a.vector_len + mc.w) * P + k;
+                a.lag[o] = (W - 1) - bestk;
+                a.cmax[o] = best / sqrt(ssa * ssb);
+            }
+        }
+        __syncthreads();                                    // the next unit has landed, this buffer is free
+        mc = mn;
+        mn = vmeta_uniform(mf);
+        mf = mg;
+        cur ^= 1;
+    }
+#undef VERIFY_QUEUE
+}
+
 __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1162,6 +1293,15 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
         if (e != hipSuccess) return e;
     }
+    // persistent double-buffered verifier (verify_dma_kernel): up to 8 elements, the unit's windows twice in LDS
+    const int vwp = (h->maxW + 3) & ~1;                                  // LDS row stride: even, >= W + 2
+    const size_t dlds = ((size_t)2 * N * vwp + 2) * sizeof(double) + (size_t)2 * h->nbands * sizeof(int);
+    const bool vdma = !h->opt.verify_global && !h->opt.verify_block && N <= 8 && h->npairs <= 32 && dlds <= 160 * 1024 &&
+                      (h->npts_pad & 1) == 0;
+    if (vdma) {
+        e = hipFuncSetAttribute((const void*)verify_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);
+        if (e != hipSuccess) return e;
+    }
     int64_t launches = 0;
     const int64_t nbatch = (h->nunits + h->screen_batch - 1) / h->screen_batch;
     if (h->prof) {
@@ -1203,7 +1343,11 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         // 8 waves: two sliding channels x 4, or one channel x 8
         hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
-        if (vlds <= 80 * 1024)
+        if (vdma) {
+            const int share = (a.nu + 7) >> 3;
+            const int per_xcd = h->num_cus > 0 ? (h->num_cus + 7) / 8 : 32;      // one workgroup per CU
+            hipLaunchKernelGGL(verify_dma_kernel, dim3(8 * (share < per_xcd ? share : per_xcd)), dim3(1024), dlds, h->stream, a, vwp, h->nbands);
+        } else if (vlds <= 80 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(512), vlds, h->stream, a);
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
