@@ -136,6 +136,13 @@ int nbls_execute(nbls_handle* h);
 /* Same, restricted to a subset of stages: bit 0 filter, bit 1 xcorr/lag pick, bit 2 solve
  * (filter only = the reference's filter_data(), helpers.py:108-141). */
 int nbls_execute_stages(nbls_handle* h, int32_t stage_mask);
+/* nbls_execute for several handles of ONE GPU whose passes are queued one after the other (the band groups of one
+ * call): the correlation stage of `h` starts when the correlation stage `prev` has queued is through (a GPU-side
+ * wait, the call itself returns at once); h's filter stage may run beside it.  The passes then finish in the order
+ * they were queued, so the caller can work on the first one's results while the later ones are still running —
+ * without this the GPU shares itself between the passes and they all finish together at the end.  Results are the
+ * same either way.  NBLS_ERR_STATE if `prev` has not queued a pass, NBLS_ERR_ARG for handles of different devices. */
+int nbls_execute_after(nbls_handle* h, nbls_handle* prev);
 int nbls_sync(nbls_handle* h);
 
 /* Copy results to host.  Any pointer may be NULL to skip it.

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('NBLS_LIB') or os.path.join(_HERE, 'csrc', 'libnbls_hi
 
 EXPORTS = [
     'nbls_version', 'nbls_device_count', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
-    'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_sync',
+    'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_execute_after', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
@@ -92,6 +92,7 @@ def load_library(path=None):
     lib.nbls_plan.argtypes = plan_args
     lib.nbls_execute.argtypes = [vp]
     lib.nbls_execute_stages.argtypes = [vp, C.c_int32]
+    lib.nbls_execute_after.argtypes = [vp, vp]
     lib.nbls_sync.argtypes = [vp]
     fetch_args = [dp, dp, dp, dp, ip, ip, dp, u8p, dp]
     lib.nbls_fetch.argtypes = [vp] + fetch_args
@@ -263,8 +264,13 @@ class Handle:
         count = np.ascontiguousarray(count, dtype=np.int32)
         self._chk(self.lib.nbls_set_window_ranges(self._h, len(first), _iptr(first), _iptr(count)))
 
-    def execute(self, stages=7):
-        self._chk(self.lib.nbls_execute_stages(self._h, int(stages)))
+    def execute(self, stages=7, after=None):
+        """Queue the pass.  ``after``: another handle of the same GPU whose pass was queued before — this pass's
+        correlation stage then starts when that one's is through (``nbls_execute_after``)."""
+        if after is not None:
+            self._chk(self.lib.nbls_execute_after(self._h, after._h))
+        else:
+            self._chk(self.lib.nbls_execute_stages(self._h, int(stages)))
 
     def sync(self):
         self._chk(self.lib.nbls_sync(self._h))

@@ -194,6 +194,7 @@ int nbls_create(int device_id, nbls_handle** out) {
     }
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) h->num_cus = 0;
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
+    if (hipEventCreateWithFlags(&h->ev_xd, hipEventDisableTiming) != hipSuccess) { h->ev_xd = nullptr; (void)hipGetLastError(); }
     *out = h;
     return NBLS_OK;
 }
@@ -211,6 +212,7 @@ void nbls_destroy(nbls_handle* h) {
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
+    if (h->ev_xd) (void)hipEventDestroy(h->ev_xd);
     if (h->up && h->up != h->stream) (void)hipStreamDestroy(h->up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -515,6 +517,16 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
 
 int nbls_execute(nbls_handle* h) { return nbls_execute_stages(h, 7); }
 
+int nbls_execute_after(nbls_handle* h, nbls_handle* prev) {
+    if (!h || !prev || prev == h) return NBLS_ERR_ARG;
+    if (prev->device != h->device) return fail(h, NBLS_ERR_ARG, "nbls_execute_after: the two handles are on different devices");
+    if (!prev->ev_xd || !prev->ev_xd_recorded) return fail(h, NBLS_ERR_STATE, "nbls_execute_after: the other handle has not queued a pass");
+    h->after = prev;
+    const int rc = nbls_execute_stages(h, 7);
+    h->after = nullptr;
+    return rc;
+}
+
 int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (!h) return NBLS_ERR_ARG;
     if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_execute: no plan");
@@ -533,7 +545,11 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     h->solve_done = false;
     h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && h->opt.overlap;
+    // nbls_execute_after: this pass's filter may run beside the other handle's correlation stage (memory-bound next to
+    // matrix-core-bound), its own correlation stage starts when the other one's is through
+    if (h->after && (stage_mask & 2)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->after->ev_xd, 0));
     if (stage_mask & 2) HIPCHK(h, nbls_launch_xcorr(h));
+    if (h->ev_xd && (stage_mask & 2)) { HIPCHK(h, hipEventRecord(h->ev_xd, h->stream)); h->ev_xd_recorded = true; }
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if ((stage_mask & 4) && !h->solve_done) HIPCHK(h, nbls_launch_solve(h));
     if (h->prof) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_valid = true; }

@@ -55,7 +55,7 @@ def pipeline_groups(nwin):
     nb = len(nwin)
     if env:
         return max(1, min(nb, int(env)))
-    return max(1, min(4, nb, int(np.sum(nwin)) // 20000))
+    return max(1, min(4, nb, int(np.sum(nwin)) // 16000))
 
 
 def stream_to_array(st):
@@ -302,11 +302,12 @@ def upload_trace(h, data, fs):
 
 
 def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0, trace_from=None,
-           trace_ready=False):
+           trace_ready=False, after=None):
     """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
     None = all) on handle ``h``.  Returns as soon as the kernels are queued.  ``trace_from``: another handle of
     the same GPU that already holds this trace (device-to-device copy instead of a second upload).
-    ``trace_ready``: the caller has already uploaded the trace to ``h`` (``upload_trace``)."""
+    ``trace_ready``: the caller has already uploaded the trace to ``h`` (``upload_trace``).  ``after``: the handle
+    of the band group queued before this one (``Handle.execute``)."""
     if upload:
         if trace_ready:
             pass
@@ -329,7 +330,7 @@ def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl
     finally:
         if window_slice is not None:
             h.set_window_ranges(None)
-    h.execute()
+    h.execute(after=after)
 
 
 def all_window_times(prep, t0_datenum):
@@ -471,9 +472,14 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                 uploader = None
                 if upload_error:
                     raise upload_error[0]
+            # the groups finish in the order they were queued (GPU-side ordering of their correlation stages): the
+            # dictionary of group k is built while groups k+1.. are still running.  Left to itself the GPU shares
+            # itself between the passes and all of them land together at the end (stream priorities alone did the
+            # job on some boxes and not on others)
+            ordered = launched and not sequential and os.environ.get('NBLS_GROUP_ORDER', '1') != '0'
             launch(h, data, prep, upload=upload, window_slice=window_slice,
                    xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
-                   trace_ready=early)
+                   trace_ready=early, after=launched[-1][0] if ordered else None)
             launched.append((h, b0, b1))
             res.handle = h
     finally:

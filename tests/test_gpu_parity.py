@@ -379,6 +379,57 @@ def test_pipelined_band_groups_equal_one_pass(monkeypatch):
             np.testing.assert_array_equal(o[4][k], outs[0][4][k])
 
 
+def test_stream_priority_and_upload_overlap_do_not_change_results(monkeypatch):
+    """The groups' handles run on prioritised streams (slot 0 highest) and the trace goes up on a helper thread while
+    the first filters are designed: scheduling only.  Every priority value is accepted (clamped to the device's
+    range), and the call gives the same tuple with both mechanisms switched off."""
+    c = _cfg('cfg2', 0.3)
+    fr = np.logspace(-2, 1, 32)
+    w = np.zeros(32)
+    args = (c['WINLEN_list'], 0.5, 0.5, c['st'], None, None, c['NBANDS'], w, w, c['freqlist'], c['band_type'], fr,
+            'butter', 2, 0.01)
+    monkeypatch.setenv('NBLS_PIPELINE_GROUPS', '3')
+    ref = narrow_band_least_squares(*args, rij=c['rij'])
+    h = engine.get_handle(None, 1)
+    try:
+        for prio in (-5, 7, 1, 0):
+            h.set_option('stream_priority', prio)
+        monkeypatch.setenv('NBLS_UPLOAD_OVERLAP', '0')
+        monkeypatch.setenv('NBLS_GROUP_ORDER', '0')          # the groups' passes not ordered on the GPU either
+        out = narrow_band_least_squares(*args, rij=c['rij'])
+    finally:
+        h.set_option('stream_priority', 0)
+    for i in (0, 1, 2, 3, 5, 7, 8):
+        np.testing.assert_array_equal(out[i], ref[i])
+    assert out[6] == ref[6] and list(out[4].keys()) == list(ref[4].keys())
+    for k in ref[4]:
+        np.testing.assert_array_equal(out[4][k], ref[4][k])
+    # nbls_execute_after: a handle cannot wait for itself, nor for a handle that has never queued a pass
+    from narrow_band_least_squares_amd._hip import Handle, NblsError
+    fresh = Handle(engine.default_device())
+    try:
+        with pytest.raises((NblsError, ValueError, RuntimeError)):
+            h.execute(after=fresh)
+        with pytest.raises((NblsError, ValueError, RuntimeError)):
+            h.execute(after=h)
+    finally:
+        fresh.close()
+
+
+def test_upload_error_surfaces_on_the_calling_thread():
+    """The helper thread's exception (rows of unequal length) is re-raised by the call, not lost."""
+    c = _cfg('cfg2', 0.1)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    rows = [np.ascontiguousarray(r) for r in data]
+    rows[2] = rows[2][:-5]
+    edges = [(0.5, 1.0), (1.0, 2.0)]
+    with pytest.raises(ValueError):
+        engine.process(rows, fs, t0, c['rij'], edges, [30.0, 30.0], 0.5, 1.0, 'butter', 2, 0.01)
+    # the handle is still usable
+    ok = engine.process(data, fs, t0, c['rij'], edges, [30.0, 30.0], 0.5, 1.0, 'butter', 2, 0.01)
+    assert np.isfinite(ok.vel[:, :int(ok.nwin[0])]).all()
+
+
 def test_window_slices_add_up_to_the_full_run():
     """Window sharding (fewer bands than GPUs): the slices of the windows processed separately are
     disjoint, keep their global row index and add up to the unsliced run bit for bit."""

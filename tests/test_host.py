@@ -206,7 +206,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip('no hipcc')
     csrc = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc')
-    want = {'xcorr_screen.hip': (['screen_kernel', 'quantize_reg_kernelILi4E', 'verify_lds_kernel'], []),
+    want = {'xcorr_screen.hip': (['screen_kernel', 'quantize_reg_kernelILi4E', 'verify_lds_kernel', 'verify_dma_kernel'], []),
             'solve.hip': (['solve_lts_wave_kernelILi28E', 'solve_ols_kernel'], ['-ffp-contract=off'])}
     for src, (kernels, flags) in want.items():
         out = tmp_path / (src + '.s')
