@@ -100,6 +100,13 @@ int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchan
 /* Same trace as another handle of the SAME device, copied device-to-device (no second trip over PCIe): the
  * band groups of one call run as concurrent passes on several handles of one GPU. */
 int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src);
+/* Two-step form of nbls_set_trace_rows for a caller that overlaps the host-to-device copy with planning:
+ * nbls_set_trace_shape declares the trace (allocation and shape, no samples), after which nbls_set_geometry and
+ * nbls_plan may be called; nbls_upload_rows copies the samples (returns when the rows may be reused) and MAY RUN ON
+ * ANOTHER THREAD meanwhile — the one exception to "one handle, one thread at a time".  nbls_execute returns
+ * NBLS_ERR_STATE until nbls_upload_rows has returned. */
+int nbls_set_trace_shape(nbls_handle* h, int32_t nchans, int64_t npts, double fs);
+int nbls_upload_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts);
 
 /* Co-array: xij[npairs][2] (km; pair k = (i,j), i<j, lexicographic; xij = r_i - r_j),
  * pair_idx[npairs][2], xpinv[2][npairs] = pseudo-inverse of xij (OLS). */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('NBLS_LIB') or os.path.join(_HERE, 'csrc', 'libnbls_hi
 
 EXPORTS = [
     'nbls_version', 'nbls_device_count', 'nbls_create', 'nbls_destroy', 'nbls_last_error', 'nbls_set_trace',
-    'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_execute_after', 'nbls_sync',
+    'nbls_set_geometry', 'nbls_plan', 'nbls_execute', 'nbls_execute_stages', 'nbls_execute_after', 'nbls_set_trace_shape', 'nbls_upload_rows', 'nbls_sync',
     'nbls_fetch', 'nbls_fetch_filtered', 'nbls_device_results', 'nbls_set_profiling',
     'nbls_get_timings', 'nbls_run', 'nbls_probe_mfma_f64', 'nbls_probe_mfma_i8', 'nbls_debug_screen_stats', 'nbls_set_window_ranges', 'nbls_debug_screen_stamps', 'nbls_debug_lts_stamps',
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
@@ -93,6 +93,8 @@ def load_library(path=None):
     lib.nbls_execute.argtypes = [vp]
     lib.nbls_execute_stages.argtypes = [vp, C.c_int32]
     lib.nbls_execute_after.argtypes = [vp, vp]
+    lib.nbls_set_trace_shape.argtypes = [vp, C.c_int32, C.c_int64, C.c_double]
+    lib.nbls_upload_rows.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int32, C.c_int64]
     lib.nbls_sync.argtypes = [vp]
     fetch_args = [dp, dp, dp, dp, ip, ip, dp, u8p, dp]
     lib.nbls_fetch.argtypes = [vp] + fetch_args
@@ -189,6 +191,26 @@ class Handle:
         ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
         self._chk(self.lib.nbls_set_trace_rows(self._h, ptrs, len(keep), npts, float(fs)))
         self.nchans, self.npts, self.fs = len(keep), npts, float(fs)
+
+    def set_trace_shape(self, nchans, npts, fs):
+        """Declare the trace (no samples yet): geometry and plan may follow while ``upload_rows`` runs on another thread."""
+        self._chk(self.lib.nbls_set_trace_shape(self._h, int(nchans), int(npts), float(fs)))
+        self.nchans, self.npts, self.fs = int(nchans), int(npts), float(fs)
+
+    def upload_rows(self, rows):
+        """The samples of the declared trace: one 1-D float64 C-contiguous array per channel."""
+        keep = []
+        for r in rows:
+            r = np.asarray(r)
+            if r.dtype != np.float64 or not r.flags.c_contiguous:
+                r = np.ascontiguousarray(r, dtype=np.float64)
+            if r.ndim != 1 or len(r) != self.npts:
+                raise ValueError('All traces must have the same number of samples.')
+            keep.append(r)
+        if len(keep) != self.nchans:
+            raise ValueError('upload_rows: %d rows for a trace declared with %d channels' % (len(keep), self.nchans))
+        ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
+        self._chk(self.lib.nbls_upload_rows(self._h, ptrs, len(keep), self.npts))
 
     def set_trace_from(self, other):
         """The trace of another handle on the same GPU, copied device-to-device."""

@@ -14,7 +14,7 @@ std::mutex g_err_mu;
 std::string g_err;   // error of a failed nbls_create
 
 int fail(nbls_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg;
+    if (h) { std::lock_guard<std::mutex> l(h->err_mu); h->err = msg; }
     else { std::lock_guard<std::mutex> l(g_err_mu); g_err = msg; }
     return code;
 }
@@ -219,8 +219,8 @@ void nbls_destroy(nbls_handle* h) {
     delete h;
 }
 
-static int set_trace_impl(nbls_handle* h, const double* const* rows, const double* flat, int32_t nchans, int64_t npts,
-                          double fs) {
+// Declare the trace: allocation and shape, no samples yet (h->trace_loaded = false).
+static int trace_shape_impl(nbls_handle* h, int32_t nchans, int64_t npts, double fs) {
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t pad = (npts + 63) / 64 * 64;
     const size_t need = (size_t)nchans * pad * sizeof(double);
@@ -229,6 +229,26 @@ static int set_trace_impl(nbls_handle* h, const double* const* rows, const doubl
         HIPCHK(h, hipMalloc((void**)&h->d_trace, need));
         h->cap_trace = need;
     }
+    if (h->nchans != nchans && h->d_xij) {      // a geometry of another array size is stale
+        (void)hipFree(h->d_xij); h->d_xij = nullptr;
+        h->caps.erase((const void*)&h->d_xij);
+        h->npairs = 0;
+    }
+    h->nchans = nchans;
+    h->npts = npts;
+    h->npts_pad = pad;
+    h->fs = fs;
+    h->planned = false;
+    h->trace_loaded = false;
+    return NBLS_OK;
+}
+
+// Copy the samples of a declared trace.  Touches only d_trace, the compute stream and (on failure) the error text:
+// nbls_upload_rows may therefore run beside nbls_set_geometry / nbls_plan of the same handle on another thread.
+static int trace_copy_impl(nbls_handle* h, const double* const* rows, const double* flat) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int32_t nchans = h->nchans;
+    const int64_t npts = h->npts, pad = h->npts_pad;
     if (pad > npts)
         HIPCHK(h, hipMemset2DAsync(h->d_trace + npts, pad * sizeof(double), 0, (pad - npts) * sizeof(double), nchans, h->stream));
     if (flat) {
@@ -241,17 +261,29 @@ static int set_trace_impl(nbls_handle* h, const double* const* rows, const doubl
     // the caller's buffers may be reused as soon as this returns (pageable sources are staged before
     // hipMemcpyAsync returns; pinned ones are still being read): wait for the copies
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->nchans != nchans && h->d_xij) {      // a geometry of another array size is stale
-        (void)hipFree(h->d_xij); h->d_xij = nullptr;
-        h->caps.erase((const void*)&h->d_xij);
-        h->npairs = 0;
-    }
-    h->nchans = nchans;
-    h->npts = npts;
-    h->npts_pad = pad;
-    h->fs = fs;
-    h->planned = false;
+    h->trace_loaded = true;
     return NBLS_OK;
+}
+
+static int set_trace_impl(nbls_handle* h, const double* const* rows, const double* flat, int32_t nchans, int64_t npts,
+                          double fs) {
+    const int rc = trace_shape_impl(h, nchans, npts, fs);
+    return rc ? rc : trace_copy_impl(h, rows, flat);
+}
+
+int nbls_set_trace_shape(nbls_handle* h, int32_t nchans, int64_t npts, double fs) {
+    if (!h) return NBLS_ERR_ARG;
+    if (nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace_shape: bad argument");
+    return trace_shape_impl(h, nchans, npts, fs);
+}
+
+int nbls_upload_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!rows || nchans != h->nchans || npts != h->npts || !h->d_trace)
+        return fail(h, NBLS_ERR_ARG, "nbls_upload_rows: rows do not match the shape declared with nbls_set_trace_shape");
+    for (int c = 0; c < nchans; ++c)
+        if (!rows[c]) return fail(h, NBLS_ERR_ARG, "nbls_upload_rows: null row");
+    return trace_copy_impl(h, rows, nullptr);
 }
 
 int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs) {
@@ -284,6 +316,7 @@ int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src) {
     h->npts_pad = src->npts_pad;
     h->fs = src->fs;
     h->planned = false;
+    h->trace_loaded = true;               // (ordered on this handle's stream before its next pass)
     return NBLS_OK;
 }
 
@@ -531,6 +564,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (!h) return NBLS_ERR_ARG;
     if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_execute: no plan");
     if ((stage_mask & 6) && !h->d_xij) return fail(h, NBLS_ERR_STATE, "nbls_execute: no geometry set");
+    if (!h->trace_loaded) return fail(h, NBLS_ERR_STATE, "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t cells = (size_t)h->nbands * h->vector_len;
     const int P = h->d_xij ? h->npairs : 1;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -57,6 +58,8 @@ struct nbls_handle {
     bool fuse_solve = false;        // set by nbls_execute_stages when correlation + solve run pipelined
     bool solve_done = false;
     std::string err;
+    std::mutex err_mu;                 // fail() may be called from the upload thread (nbls_upload_rows) too
+    bool trace_loaded = false;         // samples behind the declared shape (nbls_set_trace_shape / nbls_upload_rows)
 
     // ---- trace (HBM resident) ----
     double* d_trace = nullptr;     // [nchans][npts_pad]

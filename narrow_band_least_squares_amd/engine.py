@@ -302,12 +302,13 @@ def upload_trace(h, data, fs):
 
 
 def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0, trace_from=None,
-           trace_ready=False, after=None):
+           trace_ready=False, after=None, before_execute=None):
     """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
     None = all) on handle ``h``.  Returns as soon as the kernels are queued.  ``trace_from``: another handle of
     the same GPU that already holds this trace (device-to-device copy instead of a second upload).
     ``trace_ready``: the caller has already uploaded the trace to ``h`` (``upload_trace``).  ``after``: the handle
-    of the band group queued before this one (``Handle.execute``)."""
+    of the band group queued before this one (``Handle.execute``).  ``before_execute()``: called between plan and
+    execute (the caller joins its upload thread there)."""
     if upload:
         if trace_ready:
             pass
@@ -330,6 +331,8 @@ def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl
     finally:
         if window_slice is not None:
             h.set_window_ranges(None)
+    if before_execute is not None:
+        before_execute()
     h.execute(after=after)
 
 
@@ -412,6 +415,31 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     else:
         sequential = False
 
+    # the trace goes up (a blocking copy from pageable memory, inside the library: the GIL is released) on a helper
+    # thread while this thread designs the first group's filters AND plans its pass: the handle knows the trace's
+    # shape (set_trace_shape), only nbls_execute needs the samples
+    uploader = None
+    upload_error = []
+    if upload and handle is None and os.environ.get('NBLS_UPLOAD_OVERLAP', '1') != '0':
+        h0 = get_handle(device, 0)
+        up_rows = list(np.ascontiguousarray(data, dtype=np.float64)) if isinstance(data, np.ndarray) else data
+        h0.set_trace_shape(nchans, npts, fs)
+
+        def _upload():
+            try:
+                h0.upload_rows(up_rows)
+            except BaseException as e:            # re-raised on the calling thread below
+                upload_error.append(e)
+        uploader = threading.Thread(target=_upload, name='nbls-upload')
+        uploader.start()
+
+    def upload_done():
+        nonlocal uploader
+        if uploader is not None:
+            uploader.join()
+            uploader = None
+            if upload_error:
+                raise upload_error[0]
     P = nchans * (nchans - 1) // 2
     MB = (P + 7) // 8
     grids = np.zeros((4, nb, vector_len))
@@ -444,20 +472,6 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
 
     launched = []
     prep = None
-    # the trace goes up (a blocking copy from pageable memory, inside the library: the GIL is released) while
-    # this thread designs the first group's filters
-    uploader = None
-    upload_error = []
-    if upload and handle is None and os.environ.get('NBLS_UPLOAD_OVERLAP', '1') != '0':
-        h0 = get_handle(device, 0)
-
-        def _upload():
-            try:
-                upload_trace(h0, data, fs)
-            except BaseException as e:            # re-raised on the calling thread below
-                upload_error.append(e)
-        uploader = threading.Thread(target=_upload, name='nbls-upload')
-        uploader.start()
     try:
         for g, (b0, b1) in enumerate(bounds):
             prep = prepare(nchans, npts, fs, rij, band_edges[b0:b1], winlens[b0:b1], winover, alpha, filter_type,
@@ -467,11 +481,6 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             if sequential and launched:           # one handle, one plan at a time: finish the previous round first
                 collect(*launched.pop())
             early = uploader is not None and g == 0
-            if early:
-                uploader.join()
-                uploader = None
-                if upload_error:
-                    raise upload_error[0]
             # the groups finish in the order they were queued (GPU-side ordering of their correlation stages): the
             # dictionary of group k is built while groups k+1.. are still running.  Left to itself the GPU shares
             # itself between the passes and all of them land together at the end (stream priorities alone did the
@@ -479,11 +488,12 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             ordered = launched and not sequential and os.environ.get('NBLS_GROUP_ORDER', '1') != '0'
             launch(h, data, prep, upload=upload, window_slice=window_slice,
                    xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
-                   trace_ready=early, after=launched[-1][0] if ordered else None)
+                   trace_ready=early, after=launched[-1][0] if ordered else None,
+                   before_execute=upload_done if early else None)
             launched.append((h, b0, b1))
             res.handle = h
     finally:
-        if uploader is not None:                  # prepare() raised: do not leave the copy running behind the caller
+        if uploader is not None:                  # prepare() / plan raised: do not leave the copy running behind the caller
             uploader.join()
     finish_skeleton(prep)
     # everything is queued: host work that needs no GPU result hides behind the passes
