@@ -514,6 +514,33 @@ def time_keys(t, nwin, prefixes=None):
     return _py_time_keys(t, nwin, prefixes)
 
 
+def time_key_text(t, nwin, prefixes=None):
+    """``time_keys`` without the string objects: the key TEXT of every (band, window) as a ``(text (K, 40) uint8,
+    length (K,) uint8)`` pair, formatted in C++ with the GIL released on a few threads.  ``stdict_from_mask`` takes
+    the pair in place of the key list and makes a string only for the windows that get an entry.  Without the
+    helper module this is ``time_keys`` (a list)."""
+    if _hostext is not None and hasattr(_hostext, 'time_key_text'):
+        return _hostext.time_key_text(np.ascontiguousarray(t, dtype=np.float64), np.ascontiguousarray(nwin, dtype=np.int64),
+                                      None if prefixes is None else list(prefixes), _key_threads())
+    return _py_time_keys(t, nwin, prefixes)
+
+
+def _key_threads():
+    env = os.environ.get('NBLS_KEY_THREADS')
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(4, n - 1))
+
+
+def n_keys(keys):
+    """Number of keys in a ``time_keys`` list or a ``time_key_text`` pair."""
+    return len(keys[1]) if isinstance(keys, tuple) else len(keys)
+
+
 def _py_time_keys(t, nwin, prefixes=None):
     out = []
     for b in range(len(nwin)):
@@ -552,6 +579,9 @@ def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
 
 
 def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
+    if isinstance(keys, tuple):                                  # (text, length) of time_key_text
+        text, length = keys
+        keys = [bytes(text[i, :length[i]]).decode('ascii') for i in range(len(length))]
     pair_idx = np.asarray(pair_idx)
     P = len(pair_idx)
     B, VL, MB = mask.shape

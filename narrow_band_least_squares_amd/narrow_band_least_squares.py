@@ -81,8 +81,8 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
             h_rows[n, :] = hh
             _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
         if ALPHA < 1.0 and want_keys:
-            res.keys = engine.time_keys(res.t, res.nwin, key_prefixes)
-            res.stdict = engine.new_stdict(len(res.keys))
+            res.keys = engine.time_key_text(res.t, res.nwin, key_prefixes)
+            res.stdict = engine.new_stdict(engine.n_keys(res.keys))
 
     def group_done(res, b0, b1):
         # the dropped-element dictionary of the bands whose rows just landed, while later groups are still running

@@ -275,8 +275,27 @@ def test_host_extension_matches_python_equivalents():
                 for k in exp:
                     if k != 'size':
                         np.testing.assert_array_equal(inc[k], exp[k])
+            # key TEXT instead of key objects (formatted on 1 and 3 threads): the same text, the same dictionary
+            for nt in (1, 3):
+                text, length = ext.time_key_text(t, nwin, pre, nt)
+                assert text.shape == (len(keys), 40) and length.shape == (len(keys),)
+                assert [bytes(text[i, :length[i]]).decode('ascii') for i in range(len(keys))] == keys
+                for impl in (ext.build_stdict, engine._py_stdict_from_mask):
+                    inc = {}
+                    for b0, b1 in ((0, 2), (2, 3), (3, 5)):
+                        impl(mask[b0:b1], nwin[b0:b1], pair_idx, nch, (text, length), inc, int(nwin[:b0].sum()))
+                    assert list(inc.keys()) == list(exp.keys())
+                    assert all(type(k) is str for k in inc)
+                    for k in exp:
+                        if k != 'size':
+                            np.testing.assert_array_equal(inc[k], exp[k])
     with pytest.raises(ValueError):
         ext.build_stdict(np.zeros((1, 2, 4), np.uint8), np.array([2]), planner.pair_table(8), 8, ['a'])
+    with pytest.raises(ValueError):                          # a prefix that does not fit the 40-byte text slots
+        ext.time_key_text(np.zeros((1, 2)), np.array([2]), ['x' * 20], 1)
+    with pytest.raises(ValueError):                          # malformed key text
+        ext.build_stdict(np.zeros((1, 2, 4), np.uint8), np.array([2]), planner.pair_table(8), 8,
+                         (np.zeros((2, 39), np.uint8), np.zeros(2, np.uint8)))
 
 
 def test_one_filter_design_serves_obspy_and_scipy_forms():
@@ -442,7 +461,7 @@ def test_host_extension_under_address_and_ub_sanitizers(tmp_path):
     src = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'host_ext.cpp')
     import sysconfig
     out = str(tmp_path / '_nbls_host.so')
-    cmd = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+    cmd = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-pthread',
            '-I' + sysconfig.get_paths()['include'], '-I' + np.get_include(), src, '-o', out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -468,7 +487,15 @@ for nch in (3, 8, 16, 32):
     for b0, b1 in ((0, 1), (1, 3), (3, 4)):
         ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair, nch, keys, inc, int(nwin[:b0].sum()))
     assert list(inc) == list(d) and d['size'] == nch
-    for bad in (lambda: ext.build_stdict(mask, nwin[:2], pair, nch, keys), lambda: ext.build_stdict(mask, nwin, pair, nch, keys[:3]),
+    for nt in (1, 3):                    # key text formatted on threads, key objects made on demand
+        kt = ext.time_key_text(t, nwin, ['%%02d_' %% (b + 1) for b in range(B)], nt)
+        inc2 = {}
+        for b0, b1 in ((0, 1), (1, 3), (3, 4)):
+            ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair, nch, kt, inc2, int(nwin[:b0].sum()))
+        assert list(inc2) == list(d)
+    for bad in (lambda: ext.build_stdict(mask, nwin, pair, nch, (kt[0][:3], kt[1][:3])), lambda: ext.build_stdict(mask, nwin, pair, nch, (kt[0], kt[1][:3])),
+                lambda: ext.time_key_text(t, nwin, ['y' * 30] * B, 2), lambda: ext.time_key_text(t, nwin + 100, None, 2),
+                lambda: ext.build_stdict(mask, nwin[:2], pair, nch, keys), lambda: ext.build_stdict(mask, nwin, pair, nch, keys[:3]),
                 lambda: ext.build_stdict(np.concatenate((mask, mask), axis=-1), nwin, pair, nch, keys), lambda: ext.build_stdict(mask, nwin, pair, nch, keys, [], 0),
                 lambda: ext.build_stdict(mask, nwin, pair, nch, keys, {}, -1), lambda: ext.time_keys(t, nwin + 100, None),
                 lambda: ext.time_keys(t, nwin, ['a']), lambda: ext.time_keys(t[0], nwin, None), lambda: ext.float_repr('x')):

@@ -28,3 +28,17 @@ for rep in range(6):
     print('time_keys %.2f ms (%d keys, %.0f ns/key)  new_dict %.2f ms  stdict %.2f ms (%d entries, %.0f ns/entry)'
           % ((t1 - t0) * 1e3, len(keys), (t1 - t0) * 1e9 / len(keys), (t2 - t1) * 1e3, (t3 - t2) * 1e3, len(d), (t3 - t2) * 1e9 / len(d)))
     del d, keys
+    for nt in (1, 2, 4, 8):
+        import os
+        os.environ['NBLS_KEY_THREADS'] = str(nt)
+        t0 = time.perf_counter()
+        kt = engine.time_key_text(t, nwin, pref)
+        t1 = time.perf_counter()
+        d = engine.new_stdict(B * VL)
+        t2 = time.perf_counter()
+        for g in range(4):
+            b0, b1 = 12 * g, 12 * g + 12
+            engine.stdict_from_mask(mask[b0:b1], nwin[b0:b1], pair_idx, 8, kt, d, b0 * VL)
+        t3 = time.perf_counter()
+        print('   text keys, %d threads: key text %.2f ms  stdict %.2f ms (%d entries)' % (nt, (t1 - t0) * 1e3, (t3 - t2) * 1e3, len(d)))
+        del d, kt
