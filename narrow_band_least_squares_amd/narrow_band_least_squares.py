@@ -217,7 +217,7 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
                     _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
             t_array = engine.all_window_times(prep, t0)
             if ALPHA < 1.0:
-                keys = engine.time_keys(t_array, prep.nwin, [_band_prefix(ii + 1) for ii in bands])
+                keys = engine.time_key_text(t_array, prep.nwin, [_band_prefix(ii + 1) for ii in bands])
         except Exception as e:
             status, failure = 1, e
 
