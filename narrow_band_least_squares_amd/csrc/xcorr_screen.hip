@@ -1220,7 +1220,7 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     *CSB = round_up(*PFB + *WP + 192, 256) + 256;
     int csa = *WP + 144 + (TB - 1) * 16 * (*S);      // K round-up + read-ahead of the last tile of a group
     csa = round_up(csa, 32);
-    while (csa % 256 != 32) csa += 32;               // copy stride == 32 B (mod 256): conflict-free ds_read_b64
+    while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
     *CSA = csa;
     // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
     // LDS, else one sliding channel (4 waves, N-1 images)
