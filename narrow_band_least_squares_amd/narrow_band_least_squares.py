@@ -8,6 +8,7 @@ the GPUs of a node and collects the result blocks with one RCCL gather inside th
 (``dist.py``); with one GPU it equals the serial call.
 """
 import os
+import threading
 
 import numpy as np
 from scipy import signal
@@ -174,6 +175,25 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     status, failure, prep = 0, None, None
     by_windows = NBANDS < world or os.environ.get('NBLS_SHARD') == 'windows'
     shards = None
+    # the trace goes up to every local GPU on helper threads (the copy runs inside the library, GIL released) while
+    # this thread designs the filters of all bands; a pass is planned as soon as the design is there and queued when
+    # its GPU's copy has landed
+    uploads = []                    # (thread, error list) per local handle
+    try:
+        for hd in group.handles:
+            hd.set_trace_shape(nchans, npts, fs)
+            err = []
+
+            def _up(hd=hd, err=err):
+                try:
+                    hd.upload_rows(rows)
+                except BaseException as e:      # noqa: BLE001 - re-raised where the pass is queued
+                    err.append(e)
+            th = threading.Thread(target=_up, name='nbls-upload')
+            th.start()
+            uploads.append((th, err))
+    except Exception as e:
+        status, failure = 1, e
     try:
         if rij is None:
             rij = get_rij(lat_list, lon_list, nchans)
@@ -181,7 +201,7 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         prep = engine.prepare(nchans, npts, fs, rij, edges, [WINLEN_list[ii] for ii in bands], WINOVER, ALPHA,
                               FILTER_TYPE, FILTER_ORDER, FILTER_RIPPLE, vector_len)
     except Exception as e:          # a rank that cannot even plan still takes part in the gather (status word)
-        status, failure = 1, e
+        status, failure = 1, failure or e
     npairs = nchans * (nchans - 1) // 2
     unit_bytes = 32 + (npairs + 7) // 8
     if by_windows:
@@ -192,16 +212,26 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         nb_block = max(1, max(len(sh) for sh in shards))
     block_bytes = (nb_block * vector_len * unit_bytes + 7) // 8 * 8 + 8       # + the status word
 
+    def landed(i):
+        th, err = uploads[i]
+        th.join()
+        if err:
+            raise err[0]
+
     if status == 0:
         def start(i, hd):
             r = group.ranks[i]
             if by_windows:
-                engine.launch(hd, rows, prep, window_slice=(r, world), reserve_bytes=block_bytes)
+                engine.launch(hd, rows, prep, window_slice=(r, world), reserve_bytes=block_bytes, trace_ready=True,
+                              before_execute=lambda: landed(i))
             else:
-                engine.launch(hd, rows, prep, bands=shards[r], reserve_bytes=block_bytes)
+                engine.launch(hd, rows, prep, bands=shards[r], reserve_bytes=block_bytes, trace_ready=True,
+                              before_execute=lambda: landed(i))
         errs = [e for e in dist.run_on_handles(start, group.handles) if e is not None]
         if errs:
             status, failure = 1, errs[0]
+    for th, _ in uploads:           # (a failed rank never reached its join)
+        th.join()
 
     # host work that needs no GPU result, while the passes run
     F = len(freq_resp_list)

@@ -22,16 +22,34 @@ nbls_mod = importlib.import_module('narrow_band_least_squares_amd.narrow_band_le
 
 
 class FakeHandle:
+    """CPU stand-in of _hip.Handle for the host logic of the sharded call: records the declared trace shape and the
+    rows its upload thread delivered."""
     block = None
+    shape = None
+    uploaded = None
+
+    def set_trace_shape(self, nchans, npts, fs):
+        self.shape = (int(nchans), int(npts), float(fs))
+        self.uploaded = None
+
+    def upload_rows(self, rows):
+        assert self.shape is not None and len(rows) == self.shape[0] and all(len(r) == self.shape[1] for r in rows)
+        self.uploaded = [np.array(r) for r in rows]
 
 
 def make_fake_launch(gold, fail_rank=None, rank_of=None):
     """engine.launch stand-in: the oracle computes the share, the block is left on the fake handle."""
     edges_all = nbls_mod._band_edges(list(gold['freqlist']), str(gold['band_type']), range(len(gold['num_compute'])))
 
-    def fake_launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0):
+    def fake_launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0,
+                    trace_from=None, trace_ready=False, after=None, before_execute=None):
         if fail_rank is not None and rank_of(h) == fail_rank:
             raise ValueError('injected failure on rank %d' % fail_rank)
+        if before_execute is not None:       # the real launch joins the upload thread between plan and execute
+            before_execute()
+        if trace_ready:                      # the pass works on what the upload thread delivered
+            assert h.uploaded is not None, 'pass queued before the trace had landed'
+            data = h.uploaded
         idx = list(range(prep.nbands)) if bands is None else list(bands)
         nb, VL, MB, P = len(idx), prep.vector_len, prep.mask_bytes, prep.npairs
         grids = np.zeros((4, nb, VL))
