@@ -100,7 +100,9 @@ int nbls_set_trace_rows(nbls_handle* h, const double* const* rows, int32_t nchan
 /* Same trace as another handle of the SAME device, copied device-to-device (no second trip over PCIe): the
  * band groups of one call run as concurrent passes on several handles of one GPU. */
 int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src);
-/* Two-step form of nbls_set_trace_rows for a caller that overlaps the host-to-device copy with planning:
+
+/* Two-step form of nbls_set_trace_rows (the `st` argument, narrow_band_least_squares.py:8,43; the reference copies it
+ * per band, helpers.py:124) for a caller that overlaps the host-to-device copy with planning:
  * nbls_set_trace_shape declares the trace (allocation and shape, no samples), after which nbls_set_geometry and
  * nbls_plan may be called; nbls_upload_rows copies the samples (returns when the rows may be reused) and MAY RUN ON
  * ANOTHER THREAD meanwhile — the one exception to "one handle, one thread at a time".  nbls_execute returns
@@ -144,7 +146,7 @@ int nbls_execute(nbls_handle* h);
  * (filter only = the reference's filter_data(), helpers.py:108-141). */
 int nbls_execute_stages(nbls_handle* h, int32_t stage_mask);
 /* nbls_execute for several handles of ONE GPU whose passes are queued one after the other (the band groups of one
- * call): the correlation stage of `h` starts when the correlation stage `prev` has queued is through (a GPU-side
+ * call = consecutive iterations of the reference's band loop, narrow_band_least_squares.py:64-124): the correlation stage of `h` starts when the correlation stage `prev` has queued is through (a GPU-side
  * wait, the call itself returns at once); h's filter stage may run beside it.  The passes then finish in the order
  * they were queued, so the caller can work on the first one's results while the later ones are still running —
  * without this the GPU shares itself between the passes and they all finish together at the end.  Results are the
