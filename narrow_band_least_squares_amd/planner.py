@@ -219,7 +219,7 @@ def window_plan(npts, fs, window_length, window_overlap):
     inc = int(np.round((1 - window_overlap) * W))
     if W < 2 or inc < 1:
         raise ValueError('window length / overlap give an empty window or zero hop')
-    nwin = len(np.arange(0, npts - W, inc))
+    nwin = max(0, -(-(int(npts) - W) // inc))          # = len(np.arange(0, npts - W, inc)), without building it
     return W, inc, nwin
 
 
