@@ -7,6 +7,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -445,9 +446,22 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const int D = 2 * nsections;
     const int GG = NBLS_FILTER_GROUP;
     std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
-    for (int b = 0; b < nbands && nsections > 0; ++b)
-        filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
-                      &FW[(size_t)b * NBLS_FILTER_CHUNK * D], &M[(size_t)b * (GG + 1) * D * D]);
+    {
+        // long-double table arithmetic, 30-100 us per band: the bands are dealt to a few host threads (the first
+        // group's plan sits on the critical path of a pipelined call: the GPU has nothing to do until it is through)
+        double* const fwp = FW.data();
+        double* const mp = M.data();
+        const int nt = nsections > 0 ? (nbands >= 12 ? 4 : (nbands >= 6 ? 2 : 1)) : 0;
+        auto work = [&](int t) {
+            for (int b = t; b < nbands; b += nt)
+                filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
+                              fwp + (size_t)b * NBLS_FILTER_CHUNK * D, mp + (size_t)b * (GG + 1) * D * D);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        if (nt > 0) work(0);
+        for (auto& x : th) x.join();
+    }
     const auto tp1 = std::chrono::steady_clock::now();
     if ((rc = alloc_copy(h, &h->d_fw, FW.data(), FW.size()))) return rc;
     if ((rc = alloc_copy(h, &h->d_sos, sos, (size_t)nbands * nsections * 6))) return rc;
