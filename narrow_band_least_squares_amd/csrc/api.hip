@@ -531,6 +531,13 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         int64_t batch = (int64_t)(batch_mb << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
         if (batch > U) batch = U > 0 ? U : 1;
+        // equal batches (a multiple of 8 units, the XCD grouping of the screening grid) instead of full ones plus a
+        // remainder: a 200-unit tail batch pays four kernel launches and their drain for next to nothing
+        if (U > batch) {
+            const int64_t nb_ = (U + batch - 1) / batch;
+            int64_t eq = ((U + nb_ - 1) / nb_ + 7) / 8 * 8;
+            if (eq < batch) batch = eq;
+        }
         h->screen_batch = batch;
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
         if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (10 + WP_ / 32) * sizeof(double)))) return rc;
