@@ -16,5 +16,6 @@ for rep in range(30):
         out = narrow_band_least_squares(*args, rij=c['rij'])
     ts.append((time.perf_counter() - t) * 1e3)
     del out
+print(' '.join('%.1f' % x for x in ts))
 print('groups=%s split=%s: median %.2f  min %.2f  max %.2f ms' % (os.environ.get('NBLS_PIPELINE_GROUPS'), os.environ.get('NBLS_PIPELINE_SPLIT'),
                                                                    np.median(ts[5:]), min(ts[5:]), max(ts[5:])))
