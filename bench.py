@@ -202,11 +202,12 @@ def main():
             if lts_:
                 res.keys = engine.time_key_text(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
                 res.stdict = engine.new_stdict(engine.n_keys(res.keys))
+                res.pattern_cache = engine.new_pattern_cache()
 
         def group_done(res, b0, b1):
             if lts_:
                 engine.stdict_from_mask(res.mask[b0:b1], res.nwin[b0:b1], res.pair_idx, res.nchans, res.keys,
-                                        into=res.stdict, k0=int(np.sum(res.nwin[:b0])))
+                                        into=res.stdict, k0=int(np.sum(res.nwin[:b0])), cache=res.pattern_cache)
         res = engine.process(rows, fs_, t0, rij, edges, winlens, c['overlap'], c['alpha'], c['ftype'], c['order'],
                              c['ripple'], vector_len=vl, host_overlap=host_side, group_done=group_done)
         return (res.vel, res.baz, res.mdccm, res.t, res.stdict if lts_ else None, res.sigma_tau, [int(x) for x in res.nwin],

@@ -244,12 +244,44 @@ PyObject* time_key_text(PyObject*, PyObject* args) {
     return out;
 }
 
+// Shared value arrays of the dropped-pair patterns, kept ACROSS the build_stdict() calls of one pipelined call (one
+// call per band group): a pattern seen in group 0 is not built again for group 1.  Lives in a capsule the caller holds
+// for the duration of its call; tied to one pair table (size and content hash), reset when another one shows up.
+struct PatternCache {
+    std::unordered_map<std::string, PyObject*> patterns;
+    std::unordered_map<uint64_t, PyObject*> patterns64;
+    npy_intp P = -1;
+    uint64_t pair_hash = 0;
+    void clear() {
+        for (auto& kv : patterns) Py_DECREF(kv.second);
+        for (auto& kv : patterns64) Py_DECREF(kv.second);
+        patterns.clear();
+        patterns64.clear();
+    }
+};
+const char* const CACHE_NAME = "narrow_band_least_squares_amd.pattern_cache";
+void cache_free(PyObject* cap) {
+    PatternCache* c = (PatternCache*)PyCapsule_GetPointer(cap, CACHE_NAME);
+    if (c) { c->clear(); delete c; }
+}
+PyObject* new_pattern_cache(PyObject*, PyObject*) {
+    PatternCache* c = new PatternCache();
+    PyObject* cap = PyCapsule_New(c, CACHE_NAME, cache_free);
+    if (!cap) delete c;
+    return cap;
+}
+
 PyObject* build_stdict(PyObject*, PyObject* args) {
-    PyObject *mask_obj, *nwin_obj, *pair_obj, *keys, *into = Py_None;
+    PyObject *mask_obj, *nwin_obj, *pair_obj, *keys, *into = Py_None, *cache_obj = Py_None;
     long nchans;
     Py_ssize_t k0 = 0;
-    if (!PyArg_ParseTuple(args, "OOOlO|On", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys, &into, &k0)) return nullptr;
+    if (!PyArg_ParseTuple(args, "OOOlO|OnO", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys, &into, &k0, &cache_obj)) return nullptr;
     if (into != Py_None && !PyDict_Check(into)) { PyErr_SetString(PyExc_TypeError, "into must be a dict or None"); return nullptr; }
+    PatternCache* cache = nullptr;
+    if (cache_obj != Py_None) {
+        cache = PyCapsule_CheckExact(cache_obj) ? (PatternCache*)PyCapsule_GetPointer(cache_obj, CACHE_NAME) : nullptr;
+        if (!cache) { PyErr_SetString(PyExc_TypeError, "cache must be None or a new_pattern_cache() object"); return nullptr; }
+    }
     // keys: the flat list of time_keys(), or the (text, length) pair of time_key_text()
     PyArrayObject *ktext = nullptr, *klen = nullptr;
     if (PyTuple_Check(keys) && PyTuple_GET_SIZE(keys) == 2) {
@@ -292,8 +324,14 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
             const bool fresh = d && PyDict_Size(d) == 0;     // 'size' goes right after the first band of the first group
             size_obj = PyLong_FromLong(nchans);
             std::vector<int32_t> dropped((size_t)P);
-            std::unordered_map<std::string, PyObject*> patterns;     // mask bytes -> shared value array (owned)
-            std::unordered_map<uint64_t, PyObject*> patterns64;       // the same for up to 64 pairs: the mask IS the key
+            PatternCache local;
+            if (cache) {                        // another pair table than last time: the cached arrays do not apply
+                uint64_t ph = 1469598103934665603ull;
+                for (npy_intp i = 0; i < 2 * P; ++i) ph = (ph ^ (uint64_t)(uint32_t)pair[i]) * 1099511628211ull;
+                if (cache->P != P || cache->pair_hash != ph) { cache->clear(); cache->P = P; cache->pair_hash = ph; }
+            }
+            auto& patterns = cache ? cache->patterns : local.patterns;       // mask bytes -> shared value array (owned)
+            auto& patterns64 = cache ? cache->patterns64 : local.patterns64; // the same for up to 64 pairs: the mask IS the key
             std::string pat((size_t)MB, '\0');
             const uint8_t* last = nullptr;                            // run of equal masks: skip the lookup
             PyObject* last_arr = nullptr;
@@ -356,8 +394,7 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                 }
                 if (d && b == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
             }
-            for (auto& kv : patterns) Py_DECREF(kv.second);
-            for (auto& kv : patterns64) Py_DECREF(kv.second);
+            local.clear();                      // (a caller-held cache keeps its arrays)
             if (d && B == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
         }
     }
@@ -381,6 +418,7 @@ PyObject* new_dict(PyObject*, PyObject* arg) {
 
 PyMethodDef methods[] = {
     {"new_dict", new_dict, METH_O, "new_dict(n) -> empty dict presized for n entries"},
+    {"new_pattern_cache", new_pattern_cache, METH_NOARGS, "new_pattern_cache() -> object for build_stdict(..., cache): value arrays shared across its calls"},
     {"float_repr", float_repr, METH_O, "repr(float) computed by this module (self-test hook)"},
     {"time_keys", time_keys, METH_VARARGS, "time_keys(t, nwin, prefixes) -> flat list of key strings"},
     {"time_key_text", time_key_text, METH_VARARGS, "time_key_text(t, nwin, prefixes, nthreads=1) -> (text (K, 40) uint8, length (K,) uint8)"},

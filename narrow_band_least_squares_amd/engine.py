@@ -557,7 +557,15 @@ def new_stdict(nkeys):
     return {}
 
 
-def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
+def new_pattern_cache():
+    """Holder of the shared value arrays for the ``stdict_from_mask`` calls of ONE pipelined call (one per band group):
+    a dropped-pair pattern met in an earlier group is not built again.  None without the helper module."""
+    if _hostext is not None and hasattr(_hostext, 'new_pattern_cache'):
+        return _hostext.new_pattern_cache()
+    return None
+
+
+def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0, cache=None):
     """lts_array's dropped-element dictionary for ALL bands of a pass from the packed weight mask
     (B, VL, ceil(P/8)): key (``keys[b][w]``, see ``time_keys``) -> 1-based element numbers of both
     members of every zero-weight pair (first members, then second members), only for windows that
@@ -574,7 +582,7 @@ def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
     index in ``keys`` of this mask's first window); 'size' is only placed by the call that starts the dictionary."""
     if _hostext is not None:
         return _hostext.build_stdict(np.ascontiguousarray(mask, dtype=np.uint8), np.ascontiguousarray(nwin, dtype=np.int64),
-                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys, into, int(k0))
+                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys, into, int(k0), cache)
     return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into, k0)
 
 

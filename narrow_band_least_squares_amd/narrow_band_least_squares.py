@@ -84,12 +84,13 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
         if ALPHA < 1.0 and want_keys:
             res.keys = engine.time_key_text(res.t, res.nwin, key_prefixes)
             res.stdict = engine.new_stdict(engine.n_keys(res.keys))
+            res.pattern_cache = engine.new_pattern_cache()
 
     def group_done(res, b0, b1):
         # the dropped-element dictionary of the bands whose rows just landed, while later groups are still running
         if ALPHA < 1.0 and want_keys:
             engine.stdict_from_mask(res.mask[b0:b1], res.nwin[b0:b1], res.pair_idx, res.nchans, res.keys,
-                                    into=res.stdict, k0=int(np.sum(res.nwin[:b0])))
+                                    into=res.stdict, k0=int(np.sum(res.nwin[:b0])), cache=res.pattern_cache)
 
     res = engine.process(rows, fs, t0, rij, edges, winlens, WINOVER, ALPHA, FILTER_TYPE, FILTER_ORDER,
                          FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side, group_done=group_done)

@@ -275,6 +275,27 @@ def test_host_extension_matches_python_equivalents():
                 for k in exp:
                     if k != 'size':
                         np.testing.assert_array_equal(inc[k], exp[k])
+            # value arrays shared across the groups' calls through a caller-held cache: same dictionary, and a pattern
+            # that shows up in two groups is ONE object
+            cache = ext.new_pattern_cache()
+            inc = {}
+            for b0, b1 in ((0, 2), (2, 3), (3, 5)):
+                ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair_idx, nch, keys, inc, int(nwin[:b0].sum()), cache)
+            assert list(inc.keys()) == list(exp.keys())
+            by_bytes = {}
+            for k in exp:
+                if k != 'size':
+                    np.testing.assert_array_equal(inc[k], exp[k])
+                    assert by_bytes.setdefault(inc[k].tobytes(), inc[k]) is inc[k]
+            # the cache follows the pair table: another array size resets it instead of handing out stale arrays
+            other = planner.pair_table(4)
+            m4 = np.packbits((r.random((1, 5, len(other))) > 0.3).astype(np.uint8), axis=-1, bitorder='little')
+            k4 = ext.time_keys(t[:1, :5], np.array([5]), None)
+            d4 = ext.build_stdict(m4, np.array([5]), other, 4, k4, None, 0, cache)
+            e4 = engine._py_stdict_from_mask(m4, np.array([5]), other, 4, k4)
+            assert list(d4) == list(e4) and all(np.array_equal(d4[k], e4[k]) for k in e4)
+            with pytest.raises(TypeError):
+                ext.build_stdict(mask, nwin, pair_idx, nch, keys, None, 0, object())
             # key TEXT instead of key objects (formatted on 1 and 3 threads): the same text, the same dictionary
             for nt in (1, 3):
                 text, length = ext.time_key_text(t, nwin, pre, nt)
@@ -487,6 +508,12 @@ for nch in (3, 8, 16, 32):
     for b0, b1 in ((0, 1), (1, 3), (3, 4)):
         ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair, nch, keys, inc, int(nwin[:b0].sum()))
     assert list(inc) == list(d) and d['size'] == nch
+    cache = ext.new_pattern_cache()
+    inc3 = {}
+    for b0, b1 in ((0, 1), (1, 3), (3, 4)):
+        ext.build_stdict(mask[b0:b1], nwin[b0:b1], pair, nch, keys, inc3, int(nwin[:b0].sum()), cache)
+    assert list(inc3) == list(d)
+    del cache
     for nt in (1, 3):                    # key text formatted on threads, key objects made on demand
         kt = ext.time_key_text(t, nwin, ['%%02d_' %% (b + 1) for b in range(B)], nt)
         inc2 = {}
