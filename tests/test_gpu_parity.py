@@ -416,6 +416,35 @@ def test_stream_priority_and_upload_overlap_do_not_change_results(monkeypatch):
         fresh.close()
 
 
+def test_two_step_trace_upload_states():
+    """nbls_set_trace_shape + nbls_upload_rows: a pass cannot be queued before the samples are there, rows that do not
+    match the declared shape are refused, and the two-step form gives the rows of the one-step form."""
+    from narrow_band_least_squares_amd._hip import Handle, NblsError
+    c = _cfg('cfg2', 0.1)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    rows = [np.ascontiguousarray(r) for r in data]
+    edges = [(0.5, 1.0), (1.0, 2.0)]
+    ref = engine.process(data, fs, t0, c['rij'], edges, [30.0, 30.0], 0.5, 0.5, 'butter', 2, 0.01)
+    prep = engine.prepare(len(rows), len(rows[0]), fs, c['rij'], edges, [30.0, 30.0], 0.5, 0.5, 'butter', 2, 0.01)
+    h = Handle(engine.default_device())
+    try:
+        h.set_trace_shape(len(rows), len(rows[0]), fs)
+        with pytest.raises((NblsError, ValueError, RuntimeError)):          # planned, but no samples yet
+            engine.launch(h, rows, prep, trace_ready=True)
+        with pytest.raises(ValueError):
+            h.upload_rows(rows[:-1])                                        # a row is missing
+        with pytest.raises(ValueError):
+            h.upload_rows([r[:-1] for r in rows])                           # wrong length
+        h.upload_rows(rows)
+        engine.launch(h, rows, prep, trace_ready=True)
+        out = h.fetch_packed()
+        for k in ('vel', 'baz', 'mdccm'):
+            np.testing.assert_array_equal(out[k], getattr(ref, k))
+        np.testing.assert_array_equal(out['mask'], ref.mask)
+    finally:
+        h.close()
+
+
 def test_upload_error_surfaces_on_the_calling_thread():
     """The helper thread's exception (rows of unequal length) is re-raised by the call, not lost."""
     c = _cfg('cfg2', 0.1)
