@@ -78,6 +78,53 @@ int main(int argc, char** argv) {
         const int bad = nbls_plan(h, B, S ? sos : NULL, S, zero_phase, tl, tr, tl_n, winlen, wininc, 1, NULL, 0);
         if (bad != NBLS_ERR_ARG) { fprintf(stderr, "expected NBLS_ERR_ARG, got %d\n", bad); return 1; }
     }
+    /* the pipelined form from C: band 0 on this handle, the other bands on a second handle of the same GPU (trace
+     * copied device-to-device, correlation stage chained behind the first pass), the trace declared first and its
+     * samples uploaded after the plan; packed results must equal what nbls_run returned */
+    if (B >= 2) {
+        nbls_handle* h2 = NULL;
+        const double** rows = malloc((size_t)nchans * sizeof *rows);
+        for (int c = 0; c < nchans; ++c) rows[c] = trace + (size_t)c * npts;
+        if ((rc = nbls_create(0, &h2))) { fprintf(stderr, "second handle: %d\n", rc); return 1; }
+        if (nbls_execute_after(h2, h) != NBLS_ERR_STATE) { fprintf(stderr, "execute_after without a plan must be NBLS_ERR_STATE\n"); return 1; }
+        if ((rc = nbls_set_trace_shape(h, nchans, npts, fs)) || (rc = nbls_set_geometry(h, xij, pair, xpinv, P)) ||
+            (rc = nbls_plan(h, 1, S ? sos : NULL, S, zero_phase, tl, tr, tl_n, winlen, wininc, VL, lts_flag ? &lp : NULL, 0))) {
+            fprintf(stderr, "two-step setup: %d %s\n", rc, nbls_last_error(h));
+            return 1;
+        }
+        if (nbls_execute(h) != NBLS_ERR_STATE) { fprintf(stderr, "execute before nbls_upload_rows must be NBLS_ERR_STATE\n"); return 1; }
+        if ((rc = nbls_upload_rows(h, rows, nchans, npts)) || (rc = nbls_execute(h))) {
+            fprintf(stderr, "upload / execute: %d %s\n", rc, nbls_last_error(h));
+            return 1;
+        }
+        if ((rc = nbls_set_trace_from(h2, h)) || (rc = nbls_set_geometry(h2, xij, pair, xpinv, P)) ||
+            (rc = nbls_plan(h2, B - 1, S ? sos + (size_t)S * 6 : NULL, S, zero_phase, tl, tr, tl_n, winlen + 1, wininc + 1, VL,
+                            lts_flag ? &lp : NULL, 0)) ||
+            (rc = nbls_execute_after(h2, h))) {
+            fprintf(stderr, "second pass: %d %s\n", rc, nbls_last_error(h2));
+            return 1;
+        }
+        int64_t lay[4];
+        nbls_handle* hh[2] = {h, h2};
+        const int nb[2] = {1, B - 1};
+        size_t band0 = 0;
+        for (int g = 0; g < 2; ++g) {
+            if ((rc = nbls_result_layout(hh[g], lay))) { fprintf(stderr, "layout: %d\n", rc); return 1; }
+            unsigned char* blk = malloc((size_t)lay[2]);
+            if ((rc = nbls_fetch_packed(hh[g], blk, lay[2]))) { fprintf(stderr, "fetch_packed: %d %s\n", rc, nbls_last_error(hh[g])); return 1; }
+            const double* pg = (const double*)blk;
+            const size_t pc = (size_t)nb[g] * VL;
+            for (int q = 0; q < 3; ++q)                  /* vel, baz, mdccm (sigma_tau stays zero under LTS) */
+                for (size_t i = 0; i < pc; ++i) {
+                    const double x = pg[q * pc + i], y = grids[q * cells + band0 * VL + i];
+                    if (!(x == y || (x != x && y != y))) { fprintf(stderr, "pipelined form differs: grid %d band group %d cell %zu\n", q, g, i); return 1; }
+                }
+            free(blk);
+            band0 += (size_t)nb[g];
+        }
+        nbls_destroy(h2);
+        free(rows);
+    }
     nbls_destroy(h);
     f = fopen(argv[2], "wb");
     if (!f) { perror(argv[2]); return 2; }
