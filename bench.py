@@ -197,8 +197,9 @@ def main():
         lts_ = c['alpha'] < 1.0
 
         def host_side(res):
+            fast = planner.sosfreqz_bands(res.sos, fr, fs_)
             for n_, s_ in enumerate(res.sos):
-                w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_)
+                w_rows[n_], h_rows[n_] = signal.sosfreqz(s_, fr, fs=fs_) if fast is None else (fast[0], fast[1][n_])
             if lts_:
                 res.keys = engine.time_key_text(res.t, res.nwin, [_band_prefix(b + 1) for b in bands])
                 res.stdict = engine.new_stdict(engine.n_keys(res.keys))

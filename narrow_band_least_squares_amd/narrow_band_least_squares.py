@@ -13,7 +13,7 @@ import threading
 import numpy as np
 from scipy import signal
 
-from . import dist, engine
+from . import dist, engine, planner
 from .helpers import get_rij
 
 
@@ -76,8 +76,12 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
     h_rows = np.zeros((len(bands), len(freq_resp_list)), dtype=complex)
 
     def host_side(res):
+        fast = planner.sosfreqz_bands(res.sos, freq_resp_list, fs)      # SciPy's values (bit for bit), all bands at once
         for n, ii in enumerate(bands):
-            ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
+            if fast is None:
+                ww, hh = signal.sosfreqz(res.sos[n], freq_resp_list, fs=fs)
+            else:
+                ww, hh = fast[0], fast[1][n]
             w_rows[n, :] = ww
             h_rows[n, :] = hh
             _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])
@@ -241,8 +245,9 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     t_array = keys = None
     if status == 0:
         try:
+            fast = planner.sosfreqz_bands(prep.sos_ret, freq_resp_list, fs)
             for n, ii in enumerate(bands):
-                ww, hh = signal.sosfreqz(prep.sos_ret[n], freq_resp_list, fs=fs)
+                ww, hh = signal.sosfreqz(prep.sos_ret[n], freq_resp_list, fs=fs) if fast is None else (fast[0], fast[1][n])
                 w_array[n, :], h_array[n, :] = ww, hh
                 if 0 in group.ranks:
                     _bt_caution(WINLEN_list[ii], edges[n][0], edges[n][1])

@@ -670,3 +670,20 @@ def test_cfg4_window_shape_keeps_the_screening_correlator():
     ref = engine.process(data, 100.0, 0.0, rij, [(0.5, 5.0)], [30.0], 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=1, **kw)
     np.testing.assert_array_equal(got.lag, ref.lag)
     np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
+
+
+def test_filter_responses_on_this_host_are_scipys_bit_for_bit():
+    """The same check as tests/test_host.py's on the GPU box's CPU (another micro-architecture than the build
+    container's): the w / h rows of a whole call are scipy.signal.sosfreqz's, bit for bit."""
+    from scipy import signal
+    c = _cfg('cfg2', 0.1)
+    fr = np.logspace(-2, 1, 1000)
+    w = np.zeros(len(fr))
+    out = narrow_band_least_squares(c['WINLEN_list'], 0.5, 1.0, c['st'], None, None, c['NBANDS'], w, w, c['freqlist'], c['band_type'],
+                                    fr, 'cheby1', 2, 0.01, rij=c['rij'])
+    fs = c['fs']
+    for b in range(c['NBANDS']):
+        sos = signal.iirfilter(2, [c['freqlist'][b], c['freqlist'][b + 1]], rp=0.01, btype='band', ftype='cheby1', output='sos', fs=fs)
+        ws, hs = signal.sosfreqz(sos, fr, fs=fs)
+        assert np.array_equal(np.asarray(out[7][b]).real.view(np.uint64), ws.view(np.uint64))
+        assert np.array_equal(np.asarray(out[8][b]).view(np.uint64), hs.view(np.uint64))

@@ -576,3 +576,29 @@ def test_vectorised_filter_design_is_bitwise_scipy():
     with pytest.raises(ValueError):
         planner.design_bandpass_many('bessel', [(1.0, 2.0)], 2, 0.01, 20.0)
     assert planner.design_bandpass_many('cheby1', edges, 2, 0.01, 20.0)[0][1] is False
+
+
+def test_filter_responses_are_scipys_bit_for_bit():
+    """planner.sosfreqz_bands restates scipy.signal.sosfreqz (freqz_sos -> freqz -> polyval) with the same NumPy
+    operations on arrays of the same shape: w and h must carry SciPy's bits for every band, filter type, order and kind
+    of frequency grid; inputs it does not cover are declined (None) and go to SciPy."""
+    from scipy import signal
+    fr = np.logspace(-2, np.log10(20.0), 1000)
+    n = 0
+    for ftype in ('butter', 'cheby1'):
+        for order in (1, 2, 4):
+            for fs in (20.0, 40.0, 37.3):
+                edges = np.logspace(np.log10(0.05), np.log10(fs * 0.49), 13)
+                sos_list = [signal.iirfilter(order, [edges[i], edges[i + 1]], rp=0.01, btype='band', ftype=ftype, output='sos', fs=fs)
+                            for i in range(12)]
+                for worN in (fr, np.linspace(0.0, fs / 2, 333), np.arange(1, 9)):
+                    w, rows = planner.sosfreqz_bands(sos_list, worN, fs)
+                    for i, sos in enumerate(sos_list):
+                        ws, hs = signal.sosfreqz(sos, worN, fs=fs)
+                        assert np.array_equal(ws.view(np.uint64), w.view(np.uint64))
+                        assert np.array_equal(hs.view(np.uint64), rows[i].view(np.uint64)), (ftype, order, fs, i)
+                        n += 1
+    assert n > 600
+    assert planner.sosfreqz_bands([np.zeros((2, 6))], 512, 40.0) is None               # integer worN: SciPy's FFT branch
+    assert planner.sosfreqz_bands([np.zeros((0, 6))], fr, 40.0) is None
+    assert planner.sosfreqz_bands([np.zeros((2, 6), dtype=np.float32)], fr, 40.0) is None
