@@ -603,8 +603,9 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     // nbls_execute_after: this pass's filter may run beside the other handle's correlation stage (memory-bound next to
     // matrix-core-bound), its own correlation stage starts when the other one's is through
     if (h->after && (stage_mask & 2)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->after->ev_xd, 0));
+    h->ev_xd_by_launcher = false;
     if (stage_mask & 2) HIPCHK(h, nbls_launch_xcorr(h));
-    if (h->ev_xd && (stage_mask & 2)) { HIPCHK(h, hipEventRecord(h->ev_xd, h->stream)); h->ev_xd_recorded = true; }
+    if (h->ev_xd && (stage_mask & 2) && !h->ev_xd_by_launcher) { HIPCHK(h, hipEventRecord(h->ev_xd, h->stream)); h->ev_xd_recorded = true; }
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if ((stage_mask & 4) && !h->solve_done) HIPCHK(h, nbls_launch_solve(h));
     if (h->prof) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_valid = true; }

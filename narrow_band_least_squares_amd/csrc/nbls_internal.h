@@ -50,6 +50,7 @@ struct nbls_handle {
     hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
     hipEvent_t ev_xd = nullptr;        // recorded behind the correlation stage of every pass (nbls_execute_after)
     bool ev_xd_recorded = false;
+    bool ev_xd_by_launcher = false;    // the screening launcher recorded it ahead of its join with the solve stream
     nbls_handle* after = nullptr;      // set for the duration of nbls_execute_after
     int num_cus = 0;                   // compute units of the device (persistent grids)
     hipStream_t up = nullptr;          // plan-time table uploads (highest priority, see alloc_copy)

@@ -1367,6 +1367,9 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         }
         ++launches;
     }
+    // the correlation stage of this pass is queued: a pass chained behind it (nbls_execute_after) may start its own
+    // correlation stage here — BEFORE the join below, so that it runs beside this pass's last solve
+    if (h->ev_xd) { (void)hipEventRecord(h->ev_xd, h->stream); h->ev_xd_recorded = true; h->ev_xd_by_launcher = true; }
     if (h->fuse_solve) {       // join: everything later on `stream` sees the solves
         (void)hipEventRecord(h->pev[launches], h->stream2);
         (void)hipStreamWaitEvent(h->stream, h->pev[launches], 0);
