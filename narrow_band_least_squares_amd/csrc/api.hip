@@ -749,6 +749,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"lts_coop_threads", &nbls_options::lts_coop_threads, false},
         {"verify_global", &nbls_options::verify_global, false},
         {"verify_block", &nbls_options::verify_block, false},
+        {"screen_b_dma", &nbls_options::screen_b_dma, false},
         {"quantize_slab", &nbls_options::quantize_slab, false},
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},

@@ -26,6 +26,7 @@ struct nbls_options {
     int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
     int lts_coop_threads = 0;  // > 0: workgroup size of the cooperative LTS kernel
     int verify_global = 0;     // 1: verify candidates from global memory instead of LDS
+    int screen_b_dma = 0;      // 1: partner images of the screening kernel staged by LDS-DMA
     int verify_block = 0;      // 1: block-per-unit LDS verifier instead of the persistent double-buffered one
     int quantize_slab = 0;     // 1: the LDS-slab quantize kernel for every window length
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup

@@ -66,6 +66,7 @@ struct QArgs {
     int npg;                  // partner groups per sliding channel (1 up to 17 elements)
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
+    int b_dma;                // partner images staged by LDS-DMA
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
     int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
@@ -482,6 +483,26 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         tab_b = m[tab_k];
         if (tab_row < NSL) tab_a = m[NB];
     }
+    if (stage_on && a.b_dma) {
+        // partner images by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction straight into LDS, no
+        // registers, no ds_write); the zero padding in front of and behind the samples is written by hand
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int gfirst = PFB / 16, gvalid = WP / 16;                  // groups [gfirst, gfirst + gvalid) carry samples
+        for (int row = wv; row < nrowB; row += nwaves) {
+            const int slot = row >> 1, limb = row & 1;
+            const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
+            const int8_t* src = a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP;
+            unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[ch];
+            for (int g0 = 0; g0 < gvalid; g0 += 64) {
+                const int g = g0 + lane;
+                if (g < gvalid)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + g * 16), (lptr_t)(dst + (size_t)(gfirst + g0) * 16), 16, 0, 0);
+            }
+            for (int g = lane; g < gB; g += 64)
+                if (g < gfirst || g >= gfirst + gvalid) *(uint4*)(dst + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    } else
     if (stage_on)
     for (int row0 = wv; row0 < nrowB; row0 += 2 * nwaves) {
         for (int g0 = lane; g0 < gB; g0 += 256) {
@@ -1267,6 +1288,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     a.dyn = h->opt.screen_static ? 0 : 1;
+    a.b_dma = h->opt.screen_b_dma ? 1 : 0;
     a.ablate = h->opt.ablate;
     a.stamps = h->opt.screen_stamps ? h->d_stamps : nullptr;
     {
