@@ -234,7 +234,7 @@ int nbls_comm_destroy(nbls_handle* h);
 /* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects
  * between implementations that give IDENTICAL results (A/B timing; tests that check kernels against each other):
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
- *   "lts_generic_h", "lts_coop_threads", "verify_global", "verify_block", "screen_b_dma", "quantize_slab", "screen_nsl1", "screen_batch_mb",
+ *   "lts_generic_h", "lts_coop_threads", "verify_global", "verify_block", "screen_b_dma", "screen_kold", "quantize_slab", "screen_nsl1", "screen_batch_mb",
  *   "overlap", "filter_nofuse", "filter_nomfma";
  *   "stream_priority" (applied at once; the handle must be idle): 0 normal, > 0 lower, < 0 higher, clamped to the
  *   device's range — for several handles of one GPU whose passes run side by side.
@@ -274,7 +274,7 @@ int nbls_debug_lts_stamps(nbls_handle* h, double* out8);
 /* Developer: C-step phase of the cooperative FAST-LTS kernel (9..32 elements): out4 = mean cycles of thread 0 in
  * {selection, subset merging, sums} and the live entries summed over the iterations. */
 int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out4);
-int nbls_debug_screen_stamps(nbls_handle* h, double* out6);
+int nbls_debug_screen_stamps(nbls_handle* h, double* out8);
 
 #ifdef __cplusplus
 }

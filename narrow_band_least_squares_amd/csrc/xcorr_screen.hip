@@ -32,6 +32,7 @@
 // its lag groups; four tile steps are processed together so that the B fragments are reused.
 #include "nbls_internal.h"
 #include "wave_ops.h"
+#include "screen_kloop.inc"
 #include <cstdlib>
 
 namespace {
@@ -67,8 +68,10 @@ struct QArgs {
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     int b_dma;                // partner images staged by LDS-DMA
+    int kold;                 // previous form of the two-block K loop (fragment copies between K steps)
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
-    int8_t boff[32];          // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads)
+    unsigned long long boffp[2];   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
+                              // packed so that a per-lane lookup is a shift, not a load from the argument block
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
     int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
 }
 
 // ------------------------------------------------------------------ 2. screen
+__device__ inline int boff_of(const QArgs& a, int ch) {
+    return (int)((a.boffp[(ch >> 4) & 1] >> (4 * (ch & 15))) & 15);
+}
 __device__ inline unsigned int alignbyte(unsigned int hi, unsigned int lo, unsigned int sh) {
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
@@ -426,9 +432,13 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     int* khi = klo + 32;
     int* thS = khi + 32;                            // theta of the pair (f32 bits)
     int* qctr = thS + 32;                           // [2] next lag group of each sliding channel (dynamic dealing), + 2 pad
+    // per-channel records of the quantiser (sum x^2, sum |q|, max |x|, sum lo^2), fetched by 4N threads at the top of
+    // the kernel and read back after the staging barrier: the thresholds need them for the lane's two channels, and a
+    // per-lane fetch from global memory was a second round trip behind the staging one
+    double* metaS = (double*)(qctr + 4);            // [N][4]
     // energy tables for the lag-block pruning, f32 rounded UP: tails of the sliding channels, prefix sums of all
     const int NB = WP / 32 + 1;
-    float* tailT = (float*)(qctr + 4);              // [NSL][NB + 1]  E_i[32k .. W)
+    float* tailT = (float*)(metaS + 4 * N);         // [NSL][NB + 1]  E_i[32k .. W)
     float* cumT = tailT + NSL * (NB + 1);           // [N][NB + 1]    E_j[0 .. 32k)
     if (tid < 32) {
         gmax[tid] = (int)0x80000000;
@@ -456,6 +466,11 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const bool stage_on = !(NBLS_ABL(2));
     const int8_t* srcA = a.qbuf + (((int64_t)ul * N + (chsA < N ? chsA : 0)) * 2 + limbA) * WP;
     unsigned char* dstA = Acop + ((size_t)(hsA * 2 + limbA) * 8) * CSA;
+    double meta_v = 0.0;                              // this thread's entry of the per-channel records (tid < 4N)
+    if (tid < 4 * N) {
+        const int k = tid & 3;
+        meta_v = a.qmeta[((int64_t)ul * N + (tid >> 2)) * a.qms + (k < 3 ? k : 6 + WP / 32)];
+    }
     // first pass of the sliding rows (128 groups = 1024 samples per row pass)
     unsigned int asd[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             const int slot = row >> 1, limb = row & 1;
             const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
             const int8_t* src = a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP;
-            unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[ch];
+            unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * boff_of(a, ch);
             for (int g0 = 0; g0 < gvalid; g0 += 64) {
                 const int g = g0 + lane;
                 if (g < gvalid)
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
                 const int row = row0 + rr * nwaves;
                 const int slot = row >> 1, limb = row & 1;
                 const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
-                unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * a.boff[row < nrowB ? ch : 0];
+                unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * boff_of(a, row < nrowB ? ch : 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int g = g0 + 64 * q;
@@ -596,24 +611,31 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int s = cc / NP;
     const int cis = chan_ok ? ci : 0;
     const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);
-    const double* mi = a.qmeta + ((int64_t)ul * N + cis) * a.qms;
-    const double* mj = a.qmeta + ((int64_t)ul * N + j) * a.qms;
-    // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
-    // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
-    const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
-                            ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
-    const double lolo = sqrt(mi[6 + WP / 32] * mj[6 + WP / 32]);           // bound of the dropped LL product
-    const float theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
+    if (tid < 4 * N) metaS[tid] = meta_v;
     stamp(stp, 1);
     __syncthreads();
     stamp(stp, 2);
+    // candidate threshold: 2*eps of the quantisation bound, plus the f32 recombination error (<= 8
+    // roundings of 2^-24 relative) of two values of magnitude <= ||q_i|| ||q_j|| (Cauchy-Schwarz)
+    float theta, iabs6;
+    if (NBLS_ABL(8)) { theta = 1.0f; iabs6 = 0.0f; }
+    else {
+        const double* mi = metaS + 4 * cis;          // ss, L1, max, sum lo^2
+        const double* mj = metaS + 4 * j;
+        const double iabs = (mi[2] > 0.0 && mj[2] > 0.0)
+                                ? (double)QMAX * (double)QMAX * sqrt(mi[0] * mj[0]) / (mi[2] * mj[2]) : 0.0;
+        const double lolo = sqrt(mi[3] * mj[3]);                                // bound of the dropped LL product
+        theta = (float)(((mi[1] + mj[1]) * 1.001 + 0.5 * (double)W + 8.0 + 2.0 * lolo) * 1.0001 + 1.0e-6 * iabs);
+        iabs6 = (float)(1.0e-6 * iabs);
+    }
+
 
     const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * 8) * CSA;
     const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
     const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
     const unsigned char* pAl = Al + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);
     const int jslot = NSL == 2 ? j : jj;
-    const unsigned char* pBh = Bimg + ((size_t)jslot * 2) * CSB + 16 * a.boff[j] + PFB + 16 * g - 16 * s;   // + n'
+    const unsigned char* pBh = Bimg + ((size_t)jslot * 2) * CSB + 16 * boff_of(a, j) + PFB + 16 * g - 16 * s;   // + n'
     const unsigned char* pBl = pBh + CSB;
     int* gmaxh = gmax + 16 * half;
 
@@ -630,9 +652,6 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     // and the groups' K ranges shrink with p, so every SIMD gets the same matrix-core work
     const int nw = nwaves / NSL;                     // waves per sliding channel: 4, or 8 with one channel per workgroup
     const int wvu = __builtin_amdgcn_readfirstlane(NSL == 2 ? (half ? 3 - (wv & 3) : (wv & 3)) : wv);
-    // energy tables of the two channels of this lane's column (see quantize_kernel)
-    const double* cum_i = mi + 4;
-    const double* cum_j = mj + 4;
 
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
 // 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
@@ -673,16 +692,24 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      |I[d]| <= sqrt(E_i[d..W) * E_j[0..W-d))  for all d >= D0.  The first round (smallest lags,
     //      where the maximum usually is) establishes the maxima; far lag blocks of coherent windows are
     //      then never computed ----
-    for (int rnd = 0; chan_ok; ++rnd) {
+#ifdef NBLS_DEVELOPER
+    unsigned long long dev_kcyc = 0, dev_ksteps = 0, dev_ecyc = 0;  // cycles inside the K loops of this wave, K steps done
+#endif
+    if (NBLS_ABL(512)) return;                        // developer: everything up to the staging barrier
+    // dynamic dealing: the next lag group of this sliding channel goes to whichever of its four waves is
+    // free (ascending p: the small lags, where the maximum usually is, are started first; after pruning
+    // the groups cost very different amounts, a fixed deal leaves waves idle at the end).  The first group of a
+    // wave is its own index (no draw); the counter starts behind those.
+    for (int rnd = 0; chan_ok && !NBLS_ABL(256); ++rnd) {
         int p;
         bool may_prune;
         if (a.dyn) {
-            // dynamic dealing: the next lag group of this sliding channel goes to whichever of its four waves is
-            // free (ascending p: the small lags, where the maximum usually is, are started first; after pruning
-            // the groups cost very different amounts, a fixed deal leaves waves idle at the end)
-            int pp = 0;
-            if (lane == 0) pp = atomicAdd(&qctr[half], 1);
-            p = __builtin_amdgcn_readfirstlane(pp);
+            int pdraw = wvu;                         // (waves w and w+4 share a SIMD: the second sliding channel starts from the far end)
+            if (rnd > 0) {
+                if (lane == 0) pdraw = nw + atomicAdd(&qctr[half], 1);
+                pdraw = __builtin_amdgcn_readfirstlane(pdraw);
+            }
+            p = pdraw;
             if (p >= ngrp4) break;
             may_prune = p >= nw;
         } else {
@@ -697,12 +724,23 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             if (colvalid) {
                 const int ks = D0 / 32 < NB ? D0 / 32 : NB;
                 const int kp = (W - D0 + 31) / 32 < NB ? (W - D0 + 31) / 32 : NB;
-                const float bound = a.tab_lds ? sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f
-                                              : (float)(sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]) * (1.0 + 1e-6));
+                float bound;
+                if (a.tab_lds) bound = sqrtf(tailT[half * (NB + 1) + ks] * cumT[j * (NB + 1) + kp]) * 1.000001f;
+                else {
+                    // (tables read from global memory: the addresses are rebuilt here rather than kept in four
+                    //  registers through the K loops)
+                    int jv = j, iv = cis;
+                    asm volatile("" : "+v"(jv), "+v"(iv));
+                    const double* cum_i = a.qmeta + ((int64_t)ul * N + iv) * a.qms + 4;
+                    const double* cum_j = a.qmeta + ((int64_t)ul * N + jv) * a.qms + 4;
+                    bound = (float)(sqrt((cum_i[NB] - cum_i[ks]) * cum_j[kp]) * (1.0 + 1e-6));
+                }
                 const float gm = ord2f(gmaxh[jj]);
-                prunable = bound * 1.000001f + (float)(1.0e-6 * iabs) < gm - theta;
+                prunable = bound * 1.000001f + iabs6 < gm - theta;
             }
-            if (__all(prunable)) continue;
+            // the bound falls with the lag and the running maxima only rise: once a group cannot hold a candidate,
+            // no later group of this sliding channel can
+            if (__all(prunable)) { if (a.dyn) break; else continue; }
         }
         v4i h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0}, h3 = {0, 0, 0, 0};   // HH per tile
         v4i m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0}, m3 = {0, 0, 0, 0};   // HL + LH per tile
@@ -712,7 +750,29 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         if (!(NBLS_ABL(1))) {
         // the partner fragments of the NEXT K step are fetched while this step's products run
         v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
-        if (step == 32) {
+        if (step == 32 && !a.kold) {
+            // Two lag blocks per tile step (5..8 partners): hand-scheduled K loop, see screen_kloop.inc (generated by
+            // tools/gen_screen_kloop.py).  Tile t+2 at K step n and tile t at K step n+1 read the SAME A fragment, so
+            // the A stream is walked once and every fragment pair is multiplied by two partner fragments; nothing is
+            // copied between registers, every LDS read is requested six products ahead of its use.
+            typedef const __attribute__((address_space(3))) unsigned char* lds_cp;
+            // (the low-limb addresses are derived here from the high-limb ones, behind an opaque copy, so that they
+            //  do not occupy two more registers through the whole kernel; all four are advanced by the loop)
+            unsigned int va_h = (unsigned int)(uintptr_t)(lds_cp)pAh + D0, vb_h = (unsigned int)(uintptr_t)(lds_cp)pBh;
+            asm volatile("" : "+v"(va_h), "+v"(vb_h));
+            unsigned int va_l = va_h + 8 * CSA, vb_l = vb_h + CSB;
+            const int nst = (klen + 63) >> 6;
+            int kcnt;
+#ifdef NBLS_DEVELOPER
+            const unsigned long long kt0 = __builtin_amdgcn_s_memtime();
+#endif
+            NBLS_SCREEN_KLOOP_ASM(h0, m0, h1, m1, h2, m2, h3, m3, va_h, va_l, vb_h, vb_l, nst, kcnt);
+#ifdef NBLS_DEVELOPER
+            dev_kcyc += __builtin_amdgcn_s_memtime() - kt0; dev_ksteps += nst;
+#endif
+        } else if (step == 32) {
+            // (previous form of the loop, option screen_kold: the A fragments of tiles 2,3 are copied into the
+            // registers of tiles 0,1 after every K step)
             // two lag blocks per tile step (7 partners, the 8-element array): tiles t+2 and t are 64
             // bytes = one K step apart, so the A fragments of tiles 2,3 are next iteration's tiles 0,1
             // and only half of the A fragments are read from LDS per K step
@@ -769,10 +829,20 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         }
         }
         const v4i acc[TB][2] = {{h0, m0}, {h1, m1}, {h2, m2}, {h3, m3}};
+#ifdef NBLS_DEVELOPER
+        const unsigned long long et0 = __builtin_amdgcn_s_memtime();
+#endif
         SCREEN_EPILOGUE(TB, acc)
+#ifdef NBLS_DEVELOPER
+        dev_ecyc += __builtin_amdgcn_s_memtime() - et0;
+#endif
     }
 #undef SCREEN_EPILOGUE
     stamp(stp, 3);
+#ifdef NBLS_DEVELOPER
+    if (stp) { stp[6] = dev_kcyc; stp[7] = dev_ksteps + (dev_ecyc << 16); }   // (means stay separable: both parts are linear)
+#endif
+    if (NBLS_ABL(16)) return;                         // developer: no merge / candidate write
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
     stamp(stp, 4);
     int* lst = (int*)lds;                           // [2][16][KOUT] (aliases the images: they are done with)
@@ -1245,10 +1315,10 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     *CSA = csa;
     // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
     // LDS, else one sliding channel (4 waves, N-1 images)
-    // + running maxima and merge scalars (6 x 32 ints); the f32 energy tables of the pruning test are added by
+    // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
     // the caller when they still fit (nbls_screen_tables)
-    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 64;
-    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 64;
+    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 32 * N + 64;
+    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 32 * N + 64;
     const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
     if (lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
     else { *nsl = 1; *lds = lds1; }
@@ -1289,6 +1359,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.cmax = h->d_cmax;
     a.dyn = h->opt.screen_static ? 0 : 1;
     a.b_dma = h->opt.screen_b_dma ? 1 : 0;
+    a.kold = h->opt.screen_kold ? 1 : 0;
     a.ablate = h->opt.ablate;
     a.stamps = h->opt.screen_stamps ? h->d_stamps : nullptr;
     {
@@ -1304,7 +1375,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
             for (int q = 0; q < 32; ++q) cache_o[q] = o[q];
             cache_n = N;
         }
-        for (int q = 0; q < 32; ++q) a.boff[q] = (int8_t)cache_o[q];
+        a.boffp[0] = a.boffp[1] = 0;
+        for (int q = 0; q < 32; ++q) a.boffp[q >> 4] |= (unsigned long long)(cache_o[q] & 15) << (4 * (q & 15));
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
