@@ -274,7 +274,7 @@ int nbls_debug_lts_stamps(nbls_handle* h, double* out8);
 /* Developer: C-step phase of the cooperative FAST-LTS kernel (9..32 elements): out4 = mean cycles of thread 0 in
  * {selection, subset merging, sums} and the live entries summed over the iterations. */
 int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out4);
-int nbls_debug_screen_stamps(nbls_handle* h, double* out8);
+int nbls_debug_screen_stamps(nbls_handle* h, double* out10);
 
 #ifdef __cplusplus
 }

@@ -363,13 +363,10 @@ class Handle:
                     screen_ms=t.screen_ms, verify_ms=t.verify_ms, xcorr_impl=t.xcorr_impl)
 
     def screen_stamps(self):
-        out = np.zeros(8)
+        out = np.zeros(10)
         self._chk(self.lib.nbls_debug_screen_stamps(self._h, _dptr(out)))
-        d = dict(zip(('stage_issue', 'stage_wait', 'compute_wave0', 'wait_other_waves', 'merge_write', 'total',
-                      'kloop_cycles_wave0', 'ksteps_wave0'), out))
-        d['epilogue_cycles_wave0'] = float(int(out[7]) >> 16)      # packed as steps + (cycles << 16) by the kernel
-        d['ksteps_wave0'] = out[7] - d['epilogue_cycles_wave0'] * 65536.0
-        return d
+        return dict(zip(('stage_issue', 'stage_wait', 'compute_wave0', 'wait_other_waves', 'merge_write', 'total',
+                         'kloop_cycles_wave0', 'epilogue_cycles_wave0', 'epi_convert', 'epi_lds_roundtrip'), out))
 
     def lts_stamps(self):
         out = np.zeros(8)

@@ -877,8 +877,8 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
 
 int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     // mean cycle counts of the screen kernel's phases over the workgroups of the last batch:
-    // out[8] = {stage issue, stage barrier wait, compute (wave 0), wait for the other waves, merge+write, total,
-    //           cycles inside the K loops of wave 0, K steps of wave 0}
+    // out[10] = {stage issue, stage barrier wait, compute (wave 0), wait for the other waves, merge+write, total,
+    //            wave 0: cycles inside the K loops, in the epilogues, of those: conversion + maximum, shared-maximum round trip}
     if (!h || !out6) return NBLS_ERR_ARG;
     if (!h->d_stamps) return fail(h, NBLS_ERR_STATE, "run with NBLS_SCREEN_STAMPS=1");
     HIPCHK(h, hipSetDevice(h->device));
@@ -887,18 +887,20 @@ int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     const int64_t nwg = ((last + 7) / 8) * 8 * h->nchans;   // upper bound (one or two channels per workgroup)
     std::vector<unsigned long long> st((size_t)nwg * 8);
     HIPCHK(h, copy_sync(h, st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) out6[i] = 0.0;
+    for (int i = 0; i < 10; ++i) out6[i] = 0.0;
     int64_t cnt = 0;
     for (int64_t g = 0; g < nwg; ++g) {
         const unsigned long long* s = &st[(size_t)g * 8];
         if (s[5] <= s[0] || s[5] - s[0] > 100000000ull) continue;
         for (int i = 0; i < 5; ++i) out6[i] += (double)(s[i + 1] - s[i]);
         out6[5] += (double)(s[5] - s[0]);
-        out6[6] += (double)s[6];                  // cycles inside the K loops (wave 0), K steps
-        out6[7] += (double)s[7];
+        out6[6] += (double)(s[6] & 0xffffffffull);    // wave 0: cycles inside the K loops | in the epilogues
+        out6[7] += (double)(s[6] >> 32);
+        out6[8] += (double)(s[7] & 0xffffffffull);    // of the epilogues: conversion + maximum | shared-maximum round trip
+        out6[9] += (double)(s[7] >> 32);
         ++cnt;
     }
-    for (int i = 0; i < 8; ++i) out6[i] /= (double)(cnt > 0 ? cnt : 1);
+    for (int i = 0; i < 10; ++i) out6[i] /= (double)(cnt > 0 ? cnt : 1);
     return NBLS_OK;
 }
 

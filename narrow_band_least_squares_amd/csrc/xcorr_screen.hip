@@ -68,6 +68,7 @@ struct QArgs {
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     int b_dma;                // partner images staged by LDS-DMA
+    unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
     int kold;                 // previous form of the two-block K loop (fragment copies between K steps)
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
     unsigned long long boffp[2];   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
@@ -340,6 +341,18 @@ __device__ inline unsigned int alignbyte(unsigned int hi, unsigned int lo, unsig
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
+// select by a wave-wide lane mask held in scalar registers: one v_cndmask, no per-lane predicate arithmetic
+__device__ inline float sel_f32(unsigned long long m, float if_set, float if_clear) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ inline int sel_i32(unsigned long long m, int if_set, int if_clear) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+
 // order-preserving float <-> int (for integer atomicMax on LDS)
 __device__ inline int f2ord(float f) {
     const int b = __float_as_int(f);
@@ -356,8 +369,9 @@ __device__ inline float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x
 
 // Developer build only (-DNBLS_DEVELOPER): phase stamps and ablation switches; compiled out of the shipped kernels.
 #ifdef NBLS_DEVELOPER
+__device__ int nbls_dev_realtime = 0;        // screen_stamps = 2: phase stamps from the constant 100 MHz clock (wall time)
 __device__ inline void stamp(unsigned long long* p, int slot) {
-    if (p) { p[slot] = __builtin_amdgcn_s_memtime(); }
+    if (p) { p[slot] = nbls_dev_realtime ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); }
 }
 #define NBLS_ABL(bits) (a.ablate & (bits))
 #else
@@ -391,18 +405,19 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int lane = tid & 63, wv = tid >> 6;
     const int N = a.nchans;
     const int NSL = a.nsl;
-    const int NCP = (N + NSL - 1) / NSL;             // channel pairs (or single channels) per unit
+    const int NCP = (N + NSL - 1) >> (NSL - 1);      // channel pairs (or single channels) per unit (NSL is 1 or 2)
     const int NPG = a.npg;                           // partner groups of <= 16 partners (arrays of > 17 elements)
-    // keep the workgroups of one unit on one XCD (blockIdx % 8 says which blocks share an XCD) so that
-    // the unit's quantised window is fetched into that XCD's L2 once.  Speed only.
-    const int b = blockIdx.x;
-    const int grp = b / (8 * NCP * NPG), rem = b % (8 * NCP * NPG);
+    // keep the workgroups of one unit on one XCD (the linear block index % 8 says which blocks share an XCD; the
+    // grid is 8*NCP*NPG wide, so that is blockIdx.x % 8) so that the unit's quantised window is fetched into that
+    // XCD's L2 once.  Speed only.  Grid rows = groups of eight units: no integer division by run-time values here
+    // (they cost ~40 instructions each, and this phase shares the vector port with the other workgroup's products).
+    const int grp = blockIdx.y, rem = blockIdx.x;
     const int ul = grp * 8 + (rem & 7);
-    const int cp = (rem >> 3) % NCP;
-    const int pg = (rem >> 3) / NCP;
+    int cp = rem >> 3, pg = 0;
+    if (NPG > 1) { pg = cp / NCP; cp -= pg * NCP; }
     if (ul >= a.nu) return;
 #ifdef NBLS_DEVELOPER
-    unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* stp = (a.stamps && tid == 0) ? a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
 #else
     unsigned long long* const stp = nullptr;
 #endif
@@ -471,6 +486,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const int k = tid & 3;
         meta_v = a.qmeta[((int64_t)ul * N + (tid >> 2)) * a.qms + (k < 3 ? k : 6 + WP / 32)];
     }
+#ifdef NBLS_DEVELOPER
+    unsigned long long dev_s0 = __builtin_amdgcn_s_memtime(), dev_s1 = 0, dev_s2 = 0;
+#endif
     // first pass of the sliding rows (128 groups = 1024 samples per row pass)
     unsigned int asd[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     }
     // energy-table entry of this thread (f32 tables for the lag-block pruning): fetched now, stored after the images
     const bool tab_on = a.tab_lds && tid < (NSL + N) * (NB + 1);
-    const int tab_row = tab_on ? tid / (NB + 1) : 0, tab_k = tab_on ? tid - tab_row * (NB + 1) : 0;
+    const int tab_row = tab_on ? (int)__umulhi((unsigned)tid, a.tab_inv) : 0, tab_k = tab_on ? tid - tab_row * (NB + 1) : 0;
     double tab_a = 0.0, tab_b = 0.0;
     if (tab_on) {
         const int chs = NSL * cp + tab_row;
@@ -550,6 +568,9 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             }
         }
     }
+#ifdef NBLS_DEVELOPER
+    dev_s1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- 8 byte-shifted copies of each sliding channel: A_r[m] = q_i[m + r], r = 0..7.  A lane's
     //      16-byte fragment at byte offset r is read as two aligned ds_read_b64 from copy r & 7 ----
 #pragma unroll
@@ -586,13 +607,16 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
         }
     }
+#ifdef NBLS_DEVELOPER
+    dev_s2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- energy tables -> LDS (values fetched at the top of the kernel) ----
     if (tab_on) {
         if (tab_row < NSL) tailT[tab_row * (NB + 1) + tab_k] = __double2float_ru(tab_a - tab_b);
         else cumT[(tab_row - NSL) * (NB + 1) + tab_k] = __double2float_ru(tab_b);
     }
     for (int idx = tid + nthr; a.tab_lds && idx < (NSL + N) * (NB + 1); idx += nthr) {      // (more than nthr entries: big arrays)
-        const int row = idx / (NB + 1), k = idx - row * (NB + 1);
+        const int row = (int)__umulhi((unsigned)idx, a.tab_inv), k = idx - row * (NB + 1);
         if (row < NSL) {
             const int chs = NSL * cp + row;
             const double* m = a.qmeta + ((int64_t)ul * N + (chs < N ? chs : 0)) * a.qms + 4;
@@ -607,8 +631,10 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int ncol = NP * S;
     const bool colvalid = (c < ncol) && chan_ok;
     const int cc = (c < ncol) ? c : 0;               // idle columns mirror column 0 (LDS broadcast)
-    const int jj = cc % NP;
-    const int s = cc / NP;
+    int s = 0;                                       // cc / NP and cc % NP for cc < 16, NP >= 3: compare chain instead of a division
+#pragma unroll
+    for (int k = 1; k <= 5; ++k) s += (cc >= k * NP) ? 1 : 0;
+    const int jj = cc - s * NP;
     const int cis = chan_ok ? ci : 0;
     const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);
     if (tid < 4 * N) metaS[tid] = meta_v;
@@ -654,34 +680,51 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     const int wvu = __builtin_amdgcn_readfirstlane(NSL == 2 ? (half ? 3 - (wv & 3) : (wv & 3)) : wv);
 
 // consume NT tiles' accumulators: values in f32 (the int32 limb sums recombined; relative error <=
-// 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum
+// 2^-22, covered by theta); publish the group's maximum, then keep what can still be the maximum.
+// The vector port is what this phase competes for with the matrix products of the other waves (an MFMA holds
+// it for half of its cycles), so the rare work is kept off it: the lags are masked against the window end only in
+// the group that reaches it (wave-uniform test), and a value that passes the threshold is placed with wave-wide
+// masks in scalar registers — ballot of "slot q free or stale", AND with the lanes still to be placed, two
+// v_cndmask per slot tried, out as soon as every lane is placed (usually after the first slot) — instead of a
+// per-lane chain through all six slots.  Same placement rule as before: the first free or stale slot, else the interval.
+#ifdef NBLS_DEVELOPER
+#define DEV_ESTAMP(X) if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); X += t_ - dev_et; dev_et = t_; }
+#else
+#define DEV_ESTAMP(X)
+#endif
 #define SCREEN_EPILOGUE(NT, ACC)                                                                          \
     if (colvalid && !(NBLS_ABL(4))) {                                                                    \
         float v[NT * 4];                                                                                  \
-        float gmx = -__builtin_inff();                                                                    \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                  \
-            _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                         \
-                const int d = D0 + t * step + 16 * s + 4 * g + reg; /* i32 C/D: row = 4*(lane>>4)+reg */  \
-                const float x = 16384.0f * (float)ACC[t][0][reg] + 128.0f * (float)ACC[t][1][reg];        \
-                v[t * 4 + reg] = d < W ? x : -__builtin_inff();                                           \
-                gmx = fmaxf(gmx, v[t * 4 + reg]);                                                         \
-            }                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+            _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                                           \
+                v[t * 4 + reg] = 16384.0f * (float)ACC[t][0][reg] + 128.0f * (float)ACC[t][1][reg];       \
+        const int dlane = D0 + 16 * s + 4 * g;              /* i32 C/D layout: row = 4*(lane>>4)+reg */   \
+        if (D0 + NT * step > W) {                           /* only the group that reaches the window end */ \
+            _Pragma("unroll") for (int e = 0; e < NT * 4; ++e)                                            \
+                v[e] = dlane + (e >> 2) * step + (e & 3) < W ? v[e] : -__builtin_inff();                  \
         }                                                                                                 \
+        float gmx = v[0];                                                                                 \
+        _Pragma("unroll") for (int e = 1; e < NT * 4; ++e) gmx = fmaxf(gmx, v[e]);                        \
+        DEV_ESTAMP(dev_e1)                                                                                \
         if (gmx > lmax) { lmax = gmx; atomicMax(&gmaxh[jj], f2ord(gmx)); }                                \
         const float gm = ord2f(gmaxh[jj]);                                                                \
         if (gm > lmax) lmax = gm;                                                                         \
         const float thr = lmax - theta;                                                                   \
-        _Pragma("unroll") for (int e = 0; e < NT * 4; ++e) {                                              \
-            if (v[e] >= thr) {                                                                            \
-                const int d = D0 + (e >> 2) * step + 16 * s + 4 * g + (e & 3);                            \
-                bool placed = false;                                                                      \
-                _Pragma("unroll") for (int q = 0; q < NSLOT; ++q) {                                       \
-                    const bool take = !placed && sv[q] < thr; /* free or stale slot */                    \
-                    sv[q] = take ? v[e] : sv[q];                                                          \
-                    sd[q] = take ? d : sd[q];                                                             \
-                    placed = placed || take;                                                              \
+        DEV_ESTAMP(dev_e2)                                                                                \
+        if (__builtin_amdgcn_ballot_w64(gmx >= thr) != 0) {                                               \
+            _Pragma("unroll") for (int e = 0; e < NT * 4; ++e) {                                          \
+                unsigned long long rem = __builtin_amdgcn_ballot_w64(v[e] >= thr);                        \
+                if (rem != 0) {                                                                           \
+                    const int d = dlane + (e >> 2) * step + (e & 3);                                      \
+                    _Pragma("unroll") for (int q = 0; q < NSLOT; ++q) {                                   \
+                        const unsigned long long take = rem & __builtin_amdgcn_ballot_w64(sv[q] < thr);   \
+                        sv[q] = sel_f32(take, v[e], sv[q]);                                               \
+                        sd[q] = sel_i32(take, d, sd[q]);                                                  \
+                        rem &= ~take;                                                                     \
+                        if (rem == 0) break;                                                              \
+                    }                                                                                     \
+                    if (rem != 0 && ((rem >> lane) & 1)) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; } \
                 }                                                                                         \
-                if (!placed) { ilo = d < ilo ? d : ilo; ihi = d > ihi ? d : ihi; }                        \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     //      where the maximum usually is) establishes the maxima; far lag blocks of coherent windows are
     //      then never computed ----
 #ifdef NBLS_DEVELOPER
-    unsigned long long dev_kcyc = 0, dev_ksteps = 0, dev_ecyc = 0;  // cycles inside the K loops of this wave, K steps done
+    unsigned long long dev_kcyc = 0, dev_ksteps = 0, dev_ecyc = 0, dev_e1 = 0, dev_e2 = 0, dev_et = 0;  // cycles inside the K loops of this wave, K steps done
 #endif
     if (NBLS_ABL(512)) return;                        // developer: everything up to the staging barrier
     // dynamic dealing: the next lag group of this sliding channel goes to whichever of its four waves is
@@ -831,6 +874,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
         const v4i acc[TB][2] = {{h0, m0}, {h1, m1}, {h2, m2}, {h3, m3}};
 #ifdef NBLS_DEVELOPER
         const unsigned long long et0 = __builtin_amdgcn_s_memtime();
+        dev_et = et0;
 #endif
         SCREEN_EPILOGUE(TB, acc)
 #ifdef NBLS_DEVELOPER
@@ -840,7 +884,8 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
 #undef SCREEN_EPILOGUE
     stamp(stp, 3);
 #ifdef NBLS_DEVELOPER
-    if (stp) { stp[6] = dev_kcyc; stp[7] = dev_ksteps + (dev_ecyc << 16); }   // (means stay separable: both parts are linear)
+    if (stp) { stp[6] = dev_kcyc + (dev_ecyc << 32); stp[7] = dev_e1 + (dev_e2 << 32); (void)dev_ksteps;
+               if (NBLS_ABL(2048)) { stp[6] = (dev_s0 - stp[0]) + ((dev_s1 - dev_s0) << 32); stp[7] = (dev_s2 - dev_s1) + ((stp[1] - dev_s2) << 32); } }   // (two fields per word: their means stay separable)
 #endif
     if (NBLS_ABL(16)) return;                         // developer: no merge / candidate write
     __syncthreads();       // everyone is done with the A/B images: reuse the LDS head for the merge
@@ -1360,8 +1405,15 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.dyn = h->opt.screen_static ? 0 : 1;
     a.b_dma = h->opt.screen_b_dma ? 1 : 0;
     a.kold = h->opt.screen_kold ? 1 : 0;
+    {
+        const unsigned long long d = (unsigned long long)(a.WP / 32 + 2);      // exact for every index below 2^32 / d
+        a.tab_inv = (unsigned int)(((1ull << 32) + d - 1) / d);
+    }
     a.ablate = h->opt.ablate;
     a.stamps = h->opt.screen_stamps ? h->d_stamps : nullptr;
+#ifdef NBLS_DEVELOPER
+    { const int rt = h->opt.screen_stamps == 2 ? 1 : 0; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(nbls_dev_realtime), &rt, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
+#endif
     {
         // solved once per array size (cached); a failed/over-budget search falls back to the linear
         // skew o[jj] = jj, which is correct and at most 2-way conflicted
@@ -1435,7 +1487,7 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         // 8 waves: two sliding channels x 4, or one channel x 8
-        hipLaunchKernelGGL(screen_kernel, dim3(ngrp * 8 * ((N + a.nsl - 1) / a.nsl) * a.npg), dim3(512), lds, h->stream, a);
+        hipLaunchKernelGGL(screen_kernel, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vdma) {
             const int share = (a.nu + 7) >> 3;
