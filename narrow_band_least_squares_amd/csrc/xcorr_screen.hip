@@ -71,8 +71,9 @@ struct QArgs {
     unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
     int kold;                 // previous form of the two-block K loop (fragment copies between K steps)
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
-    unsigned long long boffp[2];   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
-                              // packed so that a per-lane lookup is a shift, not a load from the argument block
+    unsigned long long boffp0, boffp1;   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
+                              // packed so that a per-lane lookup is a select and a shift, not a load from the argument block
+                              // (two named words: indexing an array member by a lane value is such a load)
     unsigned long long* stamps; // developer: per-workgroup s_memtime stamps (NBLS_SCREEN_STAMPS=1), else NULL
     int ablate;               // developer timing switch (NBLS_ABLATE): 1 no K loop, 2 no staging, 4 no epilogue
     int32_t* cand;            // [nu][N][N][CSTRIDE]: count, overflow, kk...
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(256) void quantize_reg_kernel(QArgs a) {
 
 // ------------------------------------------------------------------ 2. screen
 __device__ inline int boff_of(const QArgs& a, int ch) {
-    return (int)((a.boffp[(ch >> 4) & 1] >> (4 * (ch & 15))) & 15);
+    const unsigned long long w = (ch & 16) ? a.boffp1 : a.boffp0;
+    const unsigned int half = (ch & 8) ? (unsigned int)(w >> 32) : (unsigned int)w;      // 32-bit shifts only
+    return (int)((half >> (4 * (ch & 7))) & 15);
 }
 __device__ inline unsigned int alignbyte(unsigned int hi, unsigned int lo, unsigned int sh) {
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
@@ -402,7 +405,9 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {
 __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgroups per CU: <= 128 VGPRs
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    // (the wave index through readfirstlane: everything derived from it — image rows, channels, row addresses of
+    //  the staging loops — is then scalar arithmetic and stays off the vector port)
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.nchans;
     const int NSL = a.nsl;
     const int NCP = (N + NSL - 1) >> (NSL - 1);      // channel pairs (or single channels) per unit (NSL is 1 or 2)
@@ -1427,8 +1432,9 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
             for (int q = 0; q < 32; ++q) cache_o[q] = o[q];
             cache_n = N;
         }
-        a.boffp[0] = a.boffp[1] = 0;
-        for (int q = 0; q < 32; ++q) a.boffp[q >> 4] |= (unsigned long long)(cache_o[q] & 15) << (4 * (q & 15));
+        a.boffp0 = a.boffp1 = 0;
+        for (int q = 0; q < 16; ++q) a.boffp0 |= (unsigned long long)(cache_o[q] & 15) << (4 * q);
+        for (int q = 16; q < 32; ++q) a.boffp1 |= (unsigned long long)(cache_o[q] & 15) << (4 * (q - 16));
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
