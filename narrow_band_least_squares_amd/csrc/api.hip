@@ -206,7 +206,7 @@ void nbls_destroy(nbls_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)nbls_comm_destroy(h);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
-                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2,
+                    h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -492,6 +492,16 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double) + 64))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate2, &h->cap_cstate2, nseries * h->nchunks * D * sizeof(double)))) return rc;
+    if (h->zero_phase && nsections > 0) {
+        // tile-boundary states of the recompute form (an eighth of the filtered buffer at two sections).  Without
+        // room for them the filter writes and re-reads the forward output instead: same results.
+        const size_t need = nseries * h->nchunks * (NBLS_FILTER_CHUNK / NBLS_FILTER_TILE) * D * sizeof(double);
+        if (need > h->cap_tstate) {
+            if (h->d_tstate) { (void)hipFree(h->d_tstate); h->d_tstate = nullptr; h->cap_tstate = 0; }
+            if (hipMalloc((void**)&h->d_tstate, need) == hipSuccess) h->cap_tstate = need;
+            else { h->d_tstate = nullptr; (void)hipGetLastError(); }
+        }
+    }
     const size_t ngroups = (size_t)((h->nchunks + NBLS_FILTER_GROUP - 1) / NBLS_FILTER_GROUP);
     if ((rc = ensure(h, &h->d_gend, &h->cap_gend, nseries * ngroups * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_gin, &h->cap_gin, nseries * ngroups * D * sizeof(double)))) return rc;
@@ -757,6 +767,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
+        {"filter_store_y1", &nbls_options::filter_store_y1, false},
         {"filter_nomfma", &nbls_options::filter_nomfma, false},
         {"ablate", &nbls_options::ablate, true},
         {"screen_stamps", &nbls_options::screen_stamps, true},

@@ -59,6 +59,10 @@ struct FilterArgs {
     const double* tl;
     const double* tr;
     int taper_len;
+    double* tstate;        // [nseries][C/T][nchunks][2S] forward states at the tile boundaries (recompute != 0)
+    int recompute;         // zero-phase without materialising the forward output: 1 = forward pass (stores the tile
+                           // states, writes no samples), 2 = backward pass (rebuilds each tile's forward output from
+                           // the raw trace and the stored state, then runs the backward recurrence over it)
     const double* init;    // [nseries][2S] state entering the first chunk (time-segmented filtering), else NULL = zero
     double* fin;           // [nseries][2S] state after the last (whole) chunk, else NULL
 };
@@ -320,6 +324,18 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         if (chunk0 * C + (int64_t)ti * T >= a.plen) break;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < T; ++i) tile[2 * i + (lane >> 5)][lane & 31] = pre[i];
+        double f1[S], f2[S];                                   // forward state entering this tile (backward pass of the recompute form)
+        if (a.recompute == 1 && chunk < a.nchunks) {
+            double* ts = a.tstate + (((int64_t)q * (C / T) + ti) * a.nchunks + chunk) * D;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { ts[2 * s] = s1[s]; ts[2 * s + 1] = s2[s]; }
+        } else if (a.recompute == 2) {
+            // backward chunk c covers forward chunk nchunks-1-c, backward tile ti its forward tile C/T-1-ti
+            const int64_t fc = a.nchunks - 1 - (chunk < a.nchunks ? chunk : a.nchunks - 1);
+            const double* ts = a.tstate + (((int64_t)q * (C / T) + (C / T - 1 - ti)) * a.nchunks + fc) * D;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { f1[s] = ts[2 * s]; f2[s] = ts[2 * s + 1]; }
+        }
         if (a.cstate_next)
             for (int idx = lane; idx < T * D; idx += 64) {
                 const int tl_ = idx / D, d = idx % D;
@@ -327,6 +343,25 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
             }
         __syncthreads();
         if (ti + 1 < C / T) fetch(ti + 1);                    // in flight while this tile is filtered
+        if (a.recompute == 2) {
+            // the tile holds RAW samples in backward order: the forward recurrence runs through it from its last
+            // column to its first (ascending time) from the stored state — the same operations on the same values
+            // as in the forward pass, so the samples are bit-identical to the ones that pass had in hand — and
+            // leaves the forward output in place; beyond the end of the trace that output counts as zero
+#pragma unroll 4
+            for (int t = T - 1; t >= 0; --t) {
+                double v = tile[lane][t];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double y = b0[s] * v + f1[s];
+                    f1[s] = (b1[s] * v - a1[s] * y) + f2[s];
+                    f2[s] = b2[s] * v - a2[s] * y;
+                    v = y;
+                }
+                const int64_t p = chunk * C + (int64_t)ti * T + t;
+                tile[lane][t] = (p < a.plen && a.plen - 1 - p < a.npts) ? v : 0.0;
+            }
+        }
 #pragma unroll 4
         for (int t = 0; t < T; ++t) {
             double v = tile[lane][t];
@@ -348,6 +383,7 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
             }
         }
         __syncthreads();
+        if (a.recompute != 1)              // (the forward pass of the recompute form writes no samples)
 #pragma unroll 4
         for (int i = 0; i < T; ++i) {
             const int row = 2 * i + (lane >> 5);
@@ -432,6 +468,14 @@ hipError_t run_filter(nbls_handle* h) {
     // every output sample in hand), which saves the backward pass's read of the whole buffer
     const bool fuse = h->zero_phase && !h->opt.filter_nofuse;
     a.cstate_next = fuse ? h->d_cstate2 : nullptr;
+    // zero-phase, recompute form: the forward output is never written.  The forward apply keeps the recurrence state
+    // at every tile boundary (2S doubles per T samples: an eighth of the output at two sections) and the backward
+    // apply rebuilds each tile's forward output from the raw trace (55 MB shared by all bands: it stays in the
+    // caches) before it runs the backward recurrence over it: one 8-byte write per sample instead of two writes
+    // and a read.
+    const bool recompute = fuse && h->d_tstate && !h->opt.filter_store_y1;
+    a.tstate = h->d_tstate;
+    a.recompute = recompute ? 1 : 0;
     hipError_t e = run_pass<S>(h, a, false);
     if (e != hipSuccess || !h->zero_phase) return e;
     // pass 2: in place, backward in time.  The backward index space is padded at its START to a whole
@@ -439,6 +483,7 @@ hipError_t run_filter(nbls_handle* h) {
     // the forward chunks: backward chunk c covers forward chunk nchunks-1-c.
     a.in = h->d_filt;
     a.in_mod = a.nseries;
+    if (recompute) { a.in = h->d_trace; a.in_mod = h->nchans; a.recompute = 2; }
     a.reverse = 1;
     a.plen = h->nchunks * C;
     a.final_pass = 1;
@@ -471,6 +516,8 @@ hipError_t run_filter_segment(nbls_handle* h, int reverse, const double* d_init,
     a.taper_len = 0;
     a.final_pass = 0;
     a.cstate_next = nullptr;
+    a.tstate = nullptr;
+    a.recompute = 0;
     a.init = d_init;
     a.fin = d_fin;
     a.out = h->d_filt;

@@ -35,6 +35,7 @@ struct nbls_options {
     int screen_batch_mb = 96;  // quantised-window bytes per unit batch
     int overlap = 0;           // 1: solve of batch k on a second stream while batch k+1 is correlated
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
+    int filter_store_y1 = 0;   // 1: zero-phase filters write the forward output and read it back (no recompute)
     int filter_nomfma = 0;     // 1: VALU state kernel
     // ---- developer build only ----
     int ablate = 0;            // skip parts of the screening / verify kernels (timing; results wrong)
@@ -110,6 +111,8 @@ struct nbls_handle {
     double* d_cstate = nullptr;    // [B*N][nchunks][D]
     double* d_cstate2 = nullptr;   // same, for the backward pass (its chunk states are produced by the forward apply)
     size_t cap_cstate2 = 0;
+    double* d_tstate = nullptr;    // [B*N][C/T][nchunks][D] forward states at the tile boundaries (zero-phase, recompute form)
+    size_t cap_tstate = 0;
     int32_t* d_lag = nullptr;      // [B][VL][P]
     double* d_cmax = nullptr;      // [B][VL][P]
     // result block, ONE allocation = one D2H copy / one RCCL gather:
