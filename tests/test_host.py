@@ -219,6 +219,36 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             assert int(m.group(1)) == 0, '%s spills %s bytes per lane' % (k, m.group(1))
 
 
+def test_generated_screen_kloop_is_current():
+    """csrc/screen_kloop.inc (the hand-scheduled K loop of the screening kernel) is what its generator prints, and
+    its schedule keeps the invariants the kernel relies on: every accumulator is written by exactly the products of
+    its tile, LDS waits never exceed the requests in flight, and the block ends with the wait states a vector read
+    of a matrix-core result needs."""
+    gen = os.path.join(ROOT, 'tools', 'gen_screen_kloop.py')
+    inc = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'screen_kloop.inc')
+    out = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True, timeout=60).stdout
+    assert out == open(inc).read()
+    body = [ln.split('"')[1].replace('\\n\\t', '') for ln in out.splitlines() if ln.strip().startswith('"')]
+    mf = [ln for ln in body if ln.startswith('v_mfma')]
+    # prologue 6 + two loop steps 24 + two tails 12
+    assert len(mf) == 42
+    for ln in mf:                      # in-place accumulation (or a literal zero as the first addend)
+        dst, a, b, c = [x.strip() for x in ln.split(' ', 1)[1].split(',')]
+        assert c in (dst, '0')
+        assert 96 <= int(dst[2:].split(':')[0]) <= 124 and 64 <= int(a[2:].split(':')[0]) <= 76 and 80 <= int(b[2:].split(':')[0]) <= 92
+    assert body[-2:] == ['s_nop 15', 's_nop 7']
+    # requests in flight never exceed what a 4-bit lgkmcnt can count
+    inflight = 0
+    for ln in body:
+        if ln.startswith('ds_read'):
+            inflight += 1
+        elif ln.startswith('s_waitcnt lgkmcnt('):
+            inflight = min(inflight, int(ln.split('(')[1].rstrip(')')))
+        elif ln in ('1:', '2:', '3:'):
+            inflight = 6               # state at the top of a step / tail: fragment pair E (4) + a partner refill (2)
+        assert inflight <= 15, ln
+
+
 def test_host_extension_matches_python_equivalents():
     """csrc/host_ext.cpp (_nbls_host): float repr identical to Python's for every kind of value, the key
     list and the dictionary identical (keys, order, values, dtype, read-only flag) to the NumPy forms."""
