@@ -234,7 +234,7 @@ int nbls_comm_destroy(nbls_handle* h);
 /* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects
  * between implementations that give IDENTICAL results (A/B timing; tests that check kernels against each other):
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
- *   "lts_generic_h", "lts_coop_threads", "verify_global", "verify_block", "screen_b_dma", "screen_kold", "quantize_slab", "screen_nsl1", "screen_batch_mb",
+ *   "lts_generic_h", "lts_coop_threads", "verify_global", "verify_block", "screen_b_dma", "screen_kold", "screen_tb4", "quantize_slab", "screen_nsl1", "screen_batch_mb",
  *   "overlap", "filter_nofuse", "filter_nomfma", "filter_store_y1";
  *   "stream_priority" (applied at once; the handle must be idle): 0 normal, > 0 lower, < 0 higher, clamped to the
  *   device's range — for several handles of one GPU whose passes run side by side.

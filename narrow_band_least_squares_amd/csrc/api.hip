@@ -764,6 +764,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},
         {"screen_kold", &nbls_options::screen_kold, false},
+        {"screen_tb4", &nbls_options::screen_tb4, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},

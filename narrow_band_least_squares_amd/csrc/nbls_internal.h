@@ -30,6 +30,7 @@ struct nbls_options {
     int verify_block = 0;      // 1: block-per-unit LDS verifier instead of the persistent double-buffered one
     int quantize_slab = 0;     // 1: the LDS-slab quantize kernel for every window length
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
+    int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
     int screen_kold = 0;       // 1: previous K loop of the two-block screening tiles (fragment copies between K steps)
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
     int screen_batch_mb = 96;  // quantised-window bytes per unit batch

@@ -402,7 +402,13 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {
 // 8 waves: two sliding channels x 4 waves, or — when the images of all channels do not fit twice — one sliding
 // channel x 8 waves (16 elements x 3000 samples: 160 KB, one workgroup per CU; 4 waves left the CU with one wave
 // per SIMD: 17.5 -> 13.7 ms at the cfg-4 shape.  16 waves were slower again: 15.5 ms).
-__global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgroups per CU: <= 128 VGPRs
+// TBV = tile steps per lag group.  4: two workgroups per CU (<= 128 VGPRs).  8: the workgroups that have a CU to
+// themselves (9+ elements with long windows: one sliding channel, images of all partners, ~160 KB of LDS) run two
+// waves per SIMD and may use 256 VGPRs: eight one-block tiles per group, hand-scheduled K loop that walks the A
+// stream once (screen_kloop.inc, NBLS_SCREEN_KLOOP_S1_ASM) — half the LDS bytes per product of the four-tile loop,
+// which ran at 83 % of the LDS bandwidth at that shape.
+template <int TBV>
+__global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) {
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
     // (the wave index through readfirstlane: everything derived from it — image rows, channels, row addresses of
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
     int ilo = 0x7fffffff, ihi = -1;      // lag interval that absorbs what does not fit the slots
     const int step = 16 * S;
     const int ntile = (W + step - 1) / step;
-    const int ngrp4 = (ntile + TB - 1) / TB;
+    const int ngrp4 = (ntile + TBV - 1) / TBV;
     // the second sliding channel deals its groups in the opposite order: waves w and w+4 share a SIMD,
     // and the groups' K ranges shrink with p, so every SIMD gets the same matrix-core work
     const int nw = nwaves / NSL;                     // waves per sliding channel: 4, or 8 with one channel per workgroup
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             if (p >= ngrp4) continue;
             may_prune = rnd > 0;
         }
-        const int D0 = TB * p * step;
+        const int D0 = TBV * p * step;
         if (may_prune && !NBLS_ABL(32)) {
             bool prunable = true;
             if (colvalid) {
@@ -790,6 +796,24 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             // no later group of this sliding channel can
             if (__all(prunable)) { if (a.dyn) break; else continue; }
         }
+        v4i acc[TBV][2];
+        if constexpr (TBV == 8) {
+            // eight one-block tiles (the host picks this instance only for S == 1): see screen_kloop.inc
+            typedef const __attribute__((address_space(3))) unsigned char* lds_cp;
+            unsigned int va_h = (unsigned int)(uintptr_t)(lds_cp)pAh + D0, vb_h = (unsigned int)(uintptr_t)(lds_cp)pBh;
+            asm volatile("" : "+v"(va_h), "+v"(vb_h));
+            unsigned int va_l = va_h + 8 * CSA, vb_l = vb_h + CSB;
+            const int nst = (W - D0 + 63) >> 6;
+            int kcnt;
+            if (!(NBLS_ABL(1))) {
+                NBLS_SCREEN_KLOOP_S1_ASM(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1],
+                                         acc[4][0], acc[4][1], acc[5][0], acc[5][1], acc[6][0], acc[6][1], acc[7][0], acc[7][1],
+                                         va_h, va_l, vb_h, vb_l, nst, kcnt);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TBV; ++t) { acc[t][0] = (v4i){0, 0, 0, 0}; acc[t][1] = (v4i){0, 0, 0, 0}; }
+            }
+        } else {
         v4i h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, h2 = {0, 0, 0, 0}, h3 = {0, 0, 0, 0};   // HH per tile
         v4i m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0}, m3 = {0, 0, 0, 0};   // HL + LH per tile
         const int klen = W - D0;
@@ -876,12 +900,14 @@ __global__ __launch_bounds__(512, 4) void screen_kernel(QArgs a) {   // 2 workgr
             bh = bhn; bl = bln;
         }
         }
-        const v4i acc[TB][2] = {{h0, m0}, {h1, m1}, {h2, m2}, {h3, m3}};
+        acc[0][0] = h0; acc[0][1] = m0; acc[1][0] = h1; acc[1][1] = m1;
+        acc[2][0] = h2; acc[2][1] = m2; acc[3][0] = h3; acc[3][1] = m3;
+        }
 #ifdef NBLS_DEVELOPER
         const unsigned long long et0 = __builtin_amdgcn_s_memtime();
         dev_et = et0;
 #endif
-        SCREEN_EPILOGUE(TB, acc)
+        SCREEN_EPILOGUE(TBV, acc)
 #ifdef NBLS_DEVELOPER
         dev_ecyc += __builtin_amdgcn_s_memtime() - et0;
 #endif
@@ -1359,7 +1385,9 @@ bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int*
     // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
     // row of room for the per-partner skew
     *CSB = round_up(*PFB + *WP + 192, 256) + 256;
-    int csa = *WP + 144 + (TB - 1) * 16 * (*S);      // K round-up + read-ahead of the last tile of a group
+    // K round-up + read-ahead of the last tile of a group (sized for the eight-tile groups of the one-block instance
+    // where it may be chosen: S == 1)
+    int csa = *WP + 144 + ((*S == 1 ? 8 : TB) - 1) * 16 * (*S);
     csa = round_up(csa, 32);
     while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
     *CSA = csa;
@@ -1437,7 +1465,10 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         for (int q = 16; q < 32; ++q) a.boffp1 |= (unsigned long long)(cache_o[q] & 15) << (4 * (q - 16));
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
-    hipError_t e = hipFuncSetAttribute((const void*)screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // eight-tile instance: one lag block per tile step and a CU per workgroup (two waves per SIMD: 256 VGPRs)
+    const bool tb8 = a.S == 1 && lds > 80 * 1024 && !h->opt.screen_tb4;
+    hipError_t e = hipFuncSetAttribute(tb8 ? (const void*)screen_kernel<8> : (const void*)screen_kernel<4>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t vlds = ((size_t)N * h->maxW + 2) * sizeof(double);   // + the zero slot
     if (h->opt.verify_global) vlds = 1u << 30;
@@ -1493,7 +1524,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         // 8 waves: two sliding channels x 4, or one channel x 8
-        hipLaunchKernelGGL(screen_kernel, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
+        if (tb8) hipLaunchKernelGGL(screen_kernel<8>, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
+        else hipLaunchKernelGGL(screen_kernel<4>, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vdma) {
             const int share = (a.nu + 7) >> 3;
