@@ -228,25 +228,36 @@ def test_generated_screen_kloop_is_current():
     inc = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'screen_kloop.inc')
     out = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True, timeout=60).stdout
     assert out == open(inc).read()
-    body = [ln.split('"')[1].replace('\\n\\t', '') for ln in out.splitlines() if ln.strip().startswith('"')]
-    mf = [ln for ln in body if ln.startswith('v_mfma')]
-    # prologue 6 + two loop steps 24 + two tails 12
-    assert len(mf) == 42
-    for ln in mf:                      # in-place accumulation (or a literal zero as the first addend)
-        dst, a, b, c = [x.strip() for x in ln.split(' ', 1)[1].split(',')]
-        assert c in (dst, '0')
-        assert 96 <= int(dst[2:].split(':')[0]) <= 124 and 64 <= int(a[2:].split(':')[0]) <= 76 and 80 <= int(b[2:].split(':')[0]) <= 92
-    assert body[-2:] == ['s_nop 15', 's_nop 7']
-    # requests in flight never exceed what a 4-bit lgkmcnt can count
-    inflight = 0
-    for ln in body:
-        if ln.startswith('ds_read'):
-            inflight += 1
-        elif ln.startswith('s_waitcnt lgkmcnt('):
-            inflight = min(inflight, int(ln.split('(')[1].rstrip(')')))
-        elif ln in ('1:', '2:', '3:'):
-            inflight = 6               # state at the top of a step / tail: fragment pair E (4) + a partner refill (2)
-        assert inflight <= 15, ln
+    macros = out.split('#define ')[1:]
+    assert [m.split('(')[0] for m in macros] == ['NBLS_SCREEN_KLOOP_ASM', 'NBLS_SCREEN_KLOOP_S1_ASM']
+    # (products, accumulator / A fragment / partner fragment register ranges) of the two-block and the one-block loop
+    want = [(42, (96, 124), (64, 76), (80, 92)), (84, (192, 252), (160, 188), (144, 156))]
+    for text, (nprod, racc, ra, rb) in zip(macros, want):
+        body = [ln.split('"')[1].replace('\\n\\t', '') for ln in text.splitlines() if ln.strip().startswith('"')]
+        mf = [ln for ln in body if ln.startswith('v_mfma')]
+        assert len(mf) == nprod
+        prev_dst = None
+        for ln in mf:                  # in-place accumulation (or a literal zero as the first addend), never back to back
+            dst, a, b, c = [x.strip() for x in ln.split(' ', 1)[1].split(',')]
+            assert c in (dst, '0')
+            assert dst != prev_dst or c == '0'
+            prev_dst = dst
+            first = lambda r: int(r[2:].split(':')[0])
+            assert racc[0] <= first(dst) <= racc[1] and ra[0] <= first(a) <= ra[1] and rb[0] <= first(b) <= rb[1]
+        assert body[-2:] == ['s_nop 15', 's_nop 7']
+        # LDS requests in flight never exceed what the 4-bit lgkmcnt can count, on every path through the block
+        inflight, at_branch = 0, {}
+        for ln in body:
+            if ln.startswith('ds_read'):
+                inflight += 1
+            elif ln.startswith('s_waitcnt lgkmcnt('):
+                inflight = min(inflight, int(ln.split('(')[1].rstrip(')')))
+            elif ln.startswith('s_cbranch_scc1 ') or ln.startswith('s_branch '):
+                tgt = ln.split()[1][0]
+                at_branch[tgt] = max(at_branch.get(tgt, 0), inflight)
+            elif ln in ('1:', '2:', '3:', '4:'):
+                inflight = max(inflight, at_branch.get(ln[0], 0))
+            assert inflight <= 15, ln
 
 
 def test_host_extension_matches_python_equivalents():
