@@ -28,6 +28,7 @@
 #include "nbls_internal.h"
 #include "wave_ops.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -247,7 +248,10 @@ __global__ void filter_carry_groups_kernel(FilterArgs a) {
 }
 
 // ---- apply: recurrence from the chunk's start state, one lane per chunk ----
-template <int S>
+// MODE (= FilterArgs::recompute, fixed at compile time so that each form carries only its own instructions: the
+// kernel is bound by instruction issue, ~50 vector instructions per sample): 0 plain pass, 1 forward pass of the
+// recompute form (tile states out, no samples), 2 its backward pass (forward output rebuilt per tile).
+template <int S, int MODE>
 __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     constexpr int D = 2 * S;
     __shared__ double tile[64][T + 1];
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     double e2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) e2[d] = 0.0;
-    // tile (64 chunks x 32 samples): instruction i moves rows 2i, 2i+1 (256-B contiguous segments)
+    // tile (64 chunks x T samples): instruction i moves the 64/T rows from (64/T) i on (8T-byte contiguous segments)
     double pre[T];
     // all 64 chunks of this workgroup inside the trace (every workgroup but one): no per-sample bounds tests
     const bool full = (chunk0 + 64) * C <= a.plen && (!a.reverse || chunk0 * C >= a.plen - a.npts) &&
@@ -305,16 +309,16 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
         if (full) {
 #pragma unroll
             for (int i = 0; i < T; ++i) {
-                const int row = 2 * i + (lane >> 5);
-                const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + (lane & 31);
+                const int row = (64 / T) * i + lane / T;
+                const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + lane % T;
                 pre[i] = in[a.reverse ? (a.plen - 1 - p) : p];
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            const int row = 2 * i + (lane >> 5);
-            const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + (lane & 31);
+            const int row = (64 / T) * i + lane / T;
+            const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + lane % T;
             const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
             pre[i] = (p < a.plen && g < a.npts) ? in[g] : 0.0;
         }
@@ -323,13 +327,13 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     for (int ti = 0; ti < C / T; ++ti) {
         if (chunk0 * C + (int64_t)ti * T >= a.plen) break;   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < T; ++i) tile[2 * i + (lane >> 5)][lane & 31] = pre[i];
+        for (int i = 0; i < T; ++i) tile[(64 / T) * i + lane / T][lane % T] = pre[i];
         double f1[S], f2[S];                                   // forward state entering this tile (backward pass of the recompute form)
-        if (a.recompute == 1 && chunk < a.nchunks) {
+        if (MODE == 1 && chunk < a.nchunks) {
             double* ts = a.tstate + (((int64_t)q * (C / T) + ti) * a.nchunks + chunk) * D;
 #pragma unroll
             for (int s = 0; s < S; ++s) { ts[2 * s] = s1[s]; ts[2 * s + 1] = s2[s]; }
-        } else if (a.recompute == 2) {
+        } else if (MODE == 2) {
             // backward chunk c covers forward chunk nchunks-1-c, backward tile ti its forward tile C/T-1-ti
             const int64_t fc = a.nchunks - 1 - (chunk < a.nchunks ? chunk : a.nchunks - 1);
             const double* ts = a.tstate + (((int64_t)q * (C / T) + (C / T - 1 - ti)) * a.nchunks + fc) * D;
@@ -343,51 +347,61 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
             }
         __syncthreads();
         if (ti + 1 < C / T) fetch(ti + 1);                    // in flight while this tile is filtered
-        if (a.recompute == 2) {
+        if constexpr (MODE == 2) {
             // the tile holds RAW samples in backward order: the forward recurrence runs through it from its last
             // column to its first (ascending time) from the stored state — the same operations on the same values
             // as in the forward pass, so the samples are bit-identical to the ones that pass had in hand — and
             // leaves the forward output in place; beyond the end of the trace that output counts as zero
+            auto rebuild = [&](auto masked) {
 #pragma unroll 4
-            for (int t = T - 1; t >= 0; --t) {
+                for (int t = T - 1; t >= 0; --t) {
+                    double v = tile[lane][t];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const double y = b0[s] * v + f1[s];
+                        f1[s] = (b1[s] * v - a1[s] * y) + f2[s];
+                        f2[s] = b2[s] * v - a2[s] * y;
+                        v = y;
+                    }
+                    if (decltype(masked)::value) {
+                        const int64_t p = chunk * C + (int64_t)ti * T + t;
+                        v = (p < a.plen && a.plen - 1 - p < a.npts) ? v : 0.0;
+                    }
+                    tile[lane][t] = v;
+                }
+            };
+            if (full) rebuild(std::false_type{}); else rebuild(std::true_type{});
+        }
+        auto recur = [&](auto masked) {
+#pragma unroll 4
+            for (int t = 0; t < T; ++t) {
                 double v = tile[lane][t];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const double y = b0[s] * v + f1[s];
-                    f1[s] = (b1[s] * v - a1[s] * y) + f2[s];
-                    f2[s] = b2[s] * v - a2[s] * y;
+                    const double y = b0[s] * v + s1[s];
+                    s1[s] = (b1[s] * v - a1[s] * y) + s2[s];
+                    s2[s] = b2[s] * v - a2[s] * y;
                     v = y;
                 }
-                const int64_t p = chunk * C + (int64_t)ti * T + t;
-                tile[lane][t] = (p < a.plen && a.plen - 1 - p < a.npts) ? v : 0.0;
-            }
-        }
-#pragma unroll 4
-        for (int t = 0; t < T; ++t) {
-            double v = tile[lane][t];
+                if (MODE != 1) tile[lane][t] = v;         // (the forward pass of the recompute form writes no samples)
+                if (a.cstate_next) {
+                    // zero-state end state of the BACKWARD pass's chunk that covers the same samples
+                    // (reversed): weight index C-1-tt; samples beyond the trace count as zeros there.  Fused
+                    // multiply-add: these sums are start states of the carry scan, not samples of the recurrence
+                    double yv = v;
+                    if (decltype(masked)::value) yv = (chunk * C + ti * T + t < a.npts) ? v : 0.0;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const double y = b0[s] * v + s1[s];
-                s1[s] = (b1[s] * v - a1[s] * y) + s2[s];
-                s2[s] = b2[s] * v - a2[s] * y;
-                v = y;
+                    for (int d = 0; d < D; ++d) e2[d] = __builtin_fma(wtile[t * D + d], yv, e2[d]);
+                }
             }
-            tile[lane][t] = v;
-            if (a.cstate_next) {
-                // zero-state end state of the BACKWARD pass's chunk that covers the same samples
-                // (reversed): weight index C-1-tt; samples beyond the trace count as zeros there
-                const int tt = ti * T + t;
-                const double yv = (chunk * C + tt < a.npts) ? v : 0.0;
-#pragma unroll
-                for (int d = 0; d < D; ++d) e2[d] += wtile[t * D + d] * yv;
-            }
-        }
+        };
+        if (full) recur(std::false_type{}); else recur(std::true_type{});
         __syncthreads();
-        if (a.recompute != 1)              // (the forward pass of the recompute form writes no samples)
+        if (MODE != 1)
 #pragma unroll 4
         for (int i = 0; i < T; ++i) {
-            const int row = 2 * i + (lane >> 5);
-            const int col = lane & 31;
+            const int row = (64 / T) * i + lane / T;
+            const int col = lane % T;
             const int64_t p = (chunk0 + row) * C + (int64_t)ti * T + col;
             const int64_t g = a.reverse ? (a.plen - 1 - p) : p;
             if (full || (p < a.plen && g < a.npts)) {
@@ -431,8 +445,10 @@ hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
     hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nseries + 63) / 64, a.ngroups), dim3(64), 0,
                        h->stream, a);
     hipLaunchKernelGGL((filter_carry_groups_kernel<S>), dim3((a.nseries + 63) / 64), dim3(64), 0, h->stream, a);
-    hipLaunchKernelGGL((filter_apply_kernel<S>), dim3((unsigned)((h->nchunks + 63) / 64), (unsigned)a.nseries),
-                       dim3(64), 0, h->stream, a);
+    const dim3 agrid((unsigned)((h->nchunks + 63) / 64), (unsigned)a.nseries);
+    if (a.recompute == 1) hipLaunchKernelGGL((filter_apply_kernel<S, 1>), agrid, dim3(64), 0, h->stream, a);
+    else if (a.recompute == 2) hipLaunchKernelGGL((filter_apply_kernel<S, 2>), agrid, dim3(64), 0, h->stream, a);
+    else hipLaunchKernelGGL((filter_apply_kernel<S, 0>), agrid, dim3(64), 0, h->stream, a);
     return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 
 #define NBLS_MAX_SECTIONS 8
 #define NBLS_FILTER_CHUNK 512      // samples per scan chunk (one lane each)
-#define NBLS_FILTER_TILE 32        // samples per LDS tile row
+#define NBLS_FILTER_TILE 16        // samples per LDS tile row
 #define NBLS_FILTER_GROUP 64       // chunks per carry group
 #define NBLS_MAX_PAIRS 512
 #define NBLS_MAX_WINDOW 10000     // samples: 2 * W * 8 B of LDS in xcorr_simple_kernel (<= 160 KB)
