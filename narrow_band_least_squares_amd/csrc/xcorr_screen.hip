@@ -1504,8 +1504,16 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
             const int gpl = (a.WP / 8 + 63) / 64;          // 8-sample groups per lane
             const size_t qlds = (size_t)4 * (a.WP / 8 + 8) * sizeof(double);
             const bool slab = h->opt.quantize_slab != 0;                        // option: the LDS-slab form
-            if (gpl <= 4 && !slab)
+            // (one instance per group count: a lane holds 8 G samples in registers, and the registers set how many
+            //  waves hide the HBM latency of this streaming kernel)
+            if (gpl <= 2 && !slab)
+                hipLaunchKernelGGL((quantize_reg_kernel<2>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
+            else if (gpl == 3 && !slab)
+                hipLaunchKernelGGL((quantize_reg_kernel<3>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
+            else if (gpl <= 4 && !slab)
                 hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
+            else if (gpl <= 6 && !slab)
+                hipLaunchKernelGGL((quantize_reg_kernel<6>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
             else if (gpl <= 8 && !slab)
                 hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
             else {
