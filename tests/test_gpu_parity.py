@@ -322,7 +322,7 @@ def test_kernel_variants_agree(monkeypatch):
 
 
 @pytest.mark.parametrize('nchans,winlen', [(3, 20.0), (4, 12.5), (5, 30.0), (7, 9.0), (9, 25.0), (12, 15.0), (16, 40.0),
-                                           (17, 10.0), (20, 12.0), (32, 15.0), (6, 12.525), (8, 12.175), (8, 51.3)])
+                                           (17, 10.0), (20, 12.0), (32, 15.0), (6, 12.525), (8, 12.175), (8, 51.3), (20, 60.0), (12, 70.0)])
 def test_correlators_agree_for_any_array_size(nchans, winlen):
     """Tile geometry depends on the element count (lag blocks per tile, partner skew, idle columns):
     the int8-screening and f64-MFMA correlators must pick the lags of the plain VALU kernel for every
