@@ -492,9 +492,13 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if ((rc = ensure(h, &h->d_filt, &h->cap_filt, nseries * h->npts_pad * sizeof(double) + 64))) return rc;
     if ((rc = ensure(h, &h->d_cstate, &h->cap_cstate, nseries * h->nchunks * D * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_cstate2, &h->cap_cstate2, nseries * h->nchunks * D * sizeof(double)))) return rc;
-    if (h->zero_phase && nsections > 0) {
-        // tile-boundary states of the recompute form (an eighth of the filtered buffer at two sections).  Without
-        // room for them the filter writes and re-reads the forward output instead: same results.
+    if (h->d_tstate && !(h->zero_phase && nsections > 0 && nsections <= 4)) {
+        (void)hipFree(h->d_tstate); h->d_tstate = nullptr; h->cap_tstate = 0;     // this plan filters in the stored form
+    }
+    if (h->zero_phase && nsections > 0 && nsections <= 4) {
+        // tile-boundary states of the recompute form (2S doubles per 16 samples: a quarter of the filtered buffer at
+        // two sections; beyond four sections they would be as large as the samples they replace, and the stored form
+        // is used).  Without room for them the filter writes and re-reads the forward output instead: same results.
         const size_t need = nseries * h->nchunks * (NBLS_FILTER_CHUNK / NBLS_FILTER_TILE) * D * sizeof(double);
         if (need > h->cap_tstate) {
             if (h->d_tstate) { (void)hipFree(h->d_tstate); h->d_tstate = nullptr; h->cap_tstate = 0; }
