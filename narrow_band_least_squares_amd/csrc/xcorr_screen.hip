@@ -642,9 +642,9 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     const int ncol = NP * S;
     const bool colvalid = (c < ncol) && chan_ok;
     const int cc = (c < ncol) ? c : 0;               // idle columns mirror column 0 (LDS broadcast)
-    int s = 0;                                       // cc / NP and cc % NP for cc < 16, NP >= 3: compare chain instead of a division
+    int s = 0;                                       // cc / NP and cc % NP for cc < 16, NP >= 2 (three elements: 8 lag blocks): compare chain instead of a division
 #pragma unroll
-    for (int k = 1; k <= 5; ++k) s += (cc >= k * NP) ? 1 : 0;
+    for (int k = 1; k <= 7; ++k) s += (cc >= k * NP) ? 1 : 0;
     const int jj = cc - s * NP;
     const int cis = chan_ok ? ci : 0;
     const int j = pgbase + jj + (pgbase + jj >= cis ? 1 : 0);

@@ -345,6 +345,23 @@ def test_correlators_agree_for_any_array_size(nchans, winlen):
         np.testing.assert_array_equal(got.baz, ref.baz)
 
 
+@pytest.mark.parametrize('nchans', [3, 4, 5, 6, 7, 9, 13, 17, 19])
+def test_screening_on_incoherent_noise_for_any_array_size(nchans):
+    """On white noise the arg-max of a pair lies anywhere among the 2W-1 lags, so every lag block of every tile column
+    (8 blocks per column with three elements, 5 with four, ... 1 from ten on) has to be right — a plane wave, whose maxima
+    sit at small lags, does not notice a wrong column mapping of the far blocks."""
+    rng = np.random.default_rng(400 + nchans)
+    rij = synthetic.array_geometry(nchans, 1.0, seed=300 + nchans)
+    data = rng.standard_normal((nchans, 5200))
+    kw = dict(want_lag=True, want_cmax=True)
+    edges = [(0.5, 4.0), (4.0, 12.0)]
+    ref = engine.process(data, 40.0, 0.0, rij, edges, [17.3, 9.0], 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=1, **kw)
+    got = engine.process(data, 40.0, 0.0, rij, edges, [17.3, 9.0], 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=3, **kw)
+    assert np.abs(ref.lag).max() > 200                      # the far lag blocks are exercised
+    np.testing.assert_array_equal(got.lag, ref.lag)
+    np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
+
+
 def test_band_passes_when_hbm_budget_is_small(monkeypatch):
     """More bands than the filtered-trace budget allows are run in consecutive passes: same rows."""
     c = _cfg('cfg1', 0.3)
