@@ -263,8 +263,12 @@ def prepare(nchans, npts, fs, rij, band_edges, winlens, winover, alpha, filter_t
     W = np.empty(nb, dtype=np.int32)
     inc = np.empty(nb, dtype=np.int32)
     nwin = np.empty(nb, dtype=np.int64)
+    plans = {}                                   # (bands usually share a few window lengths: one plan per length)
     for b in range(nb):
-        W[b], inc[b], nwin[b] = planner.window_plan(npts, fs, winlens[b], winover)
+        wl = float(winlens[b])
+        if wl not in plans:
+            plans[wl] = planner.window_plan(npts, fs, winlens[b], winover)
+        W[b], inc[b], nwin[b] = plans[wl]
     if vector_len is None:
         vector_len = max(1, int(nwin.max()))
     if nwin.max() > vector_len:
@@ -375,8 +379,12 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     nb = len(band_edges)
     cap = max_bands_per_pass(nchans, npts)
     W, inc, nwin = [np.empty(nb, dtype=t) for t in (np.int32, np.int32, np.int64)]
+    plans = {}                                   # (bands usually share a few window lengths: one plan per length)
     for b in range(nb):
-        W[b], inc[b], nwin[b] = planner.window_plan(npts, fs, winlens[b], winover)
+        wl = float(winlens[b])
+        if wl not in plans:
+            plans[wl] = planner.window_plan(npts, fs, winlens[b], winover)
+        W[b], inc[b], nwin[b] = plans[wl]
     if vector_len is None:
         vector_len = max(1, int(nwin.max()))
     if nwin.max() > vector_len:
@@ -466,8 +474,12 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     def finish_skeleton(prep):
         res.pair_idx, res.xij = prep.pair_idx, prep.xij
         tt = np.zeros((nb, vector_len))
+        rows_t = {}                              # (one row of window times per distinct window plan)
         for b in range(nb):
-            tt[b, :nwin[b]] = window_times(t0_datenum, fs, int(W[b]), int(inc[b]), int(nwin[b]))
+            key = (int(W[b]), int(inc[b]), int(nwin[b]))
+            if key not in rows_t:
+                rows_t[key] = window_times(t0_datenum, fs, *key)
+            tt[b, :nwin[b]] = rows_t[key]
         res.t = tt
 
     launched = []
