@@ -271,9 +271,10 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
 (developer build, options "screen_stamps" / "lts_stamps"): out8 = {setup+medians, elemental starts,
  * C-steps, candidate peel, refinement, finish, 0, total}. */
 int nbls_debug_lts_stamps(nbls_handle* h, double* out8);
-/* Developer: C-step phase of the cooperative FAST-LTS kernel (9..32 elements): out4 = mean cycles of thread 0 in
- * {selection, subset merging, sums} and the live entries summed over the iterations. */
-int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out4);
+/* Developer: C-step phases of the large-array FAST-LTS kernel (9..32 elements): out8 = mean cycles of thread 0 in
+ * {groups (selection + sums), subset merging, compaction}, the live entries summed over the iterations, and wave 0's
+ * {selection passes, selection cycles, sums cycles, groups taken}. */
+int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out8);
 int nbls_debug_screen_stamps(nbls_handle* h, double* out10);
 
 #ifdef __cplusplus

@@ -374,9 +374,9 @@ class Handle:
         return dict(zip(('setup_medians', 'elemental_starts', 'csteps', 'peel', 'refine', 'finish', 'nfin', 'total'), out))
 
     def lts_coop_breakdown(self):
-        out = np.zeros(4)
+        out = np.zeros(8)
         self._chk(self.lib.nbls_debug_lts_coop_breakdown(self._h, _dptr(out)))
-        return dict(zip(('select', 'merge', 'sums', 'live_entries_total'), out))
+        return dict(zip(('groups', 'merge', 'compact', 'live_entries_total', 'w0_passes', 'w0_select', 'w0_sums', 'w0_groups'), out))
 
     def screen_stats(self):
         out = (C.c_int64 * 4)()

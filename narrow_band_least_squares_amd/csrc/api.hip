@@ -208,7 +208,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -567,12 +567,15 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         h->ltsp.rew_table = nullptr;
         if ((rc = alloc_copy(h, &h->d_starts, lts->starts, (size_t)lts->nstarts * 4))) return rc;
         if ((rc = alloc_copy(h, &h->d_rew, lts->rew_table, (size_t)P + 1))) return rc;
-        std::vector<double> xs((size_t)P * 2);
+        const int PP = P + 16;                           // padding: the large-array LTS kernel fetches one block of pairs ahead
+        std::vector<double> xs((size_t)PP * 2, 0.0), xc((size_t)PP, 0.0);
         for (int k = 0; k < P; ++k) {
             xs[2 * k] = h->h_xij[2 * k] / lts->xij_mad[0];
             xs[2 * k + 1] = h->h_xij[2 * k + 1] / lts->xij_mad[1];
+            xc[k] = xs[2 * k] * xs[2 * k + 1];
         }
         if ((rc = alloc_copy(h, &h->d_xs, xs.data(), xs.size()))) return rc;
+        if ((rc = alloc_copy(h, &h->d_xc, xc.data(), xc.size()))) return rc;
     }
     h->planned = true;
     if (h->opt.plan_timing) {
@@ -941,19 +944,20 @@ int nbls_debug_lts_stamps(nbls_handle* h, double* out8) {
     return NBLS_OK;
 }
 
-int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out4) {
-    // developer: mean over the units of the cooperative LTS kernel's C-step phase, thread 0's cycles in
-    // {selection, subset merging, sums} and the number of live entries summed over the iterations
-    if (!h || !out4) return NBLS_ERR_ARG;
+int nbls_debug_lts_coop_breakdown(nbls_handle* h, double* out8) {
+    // developer: mean over the units of the large-array LTS kernel's C-step phases, thread 0's cycles in
+    // {groups (selection + sums), subset merging, compaction}, the live entries summed over the iterations, and
+    // wave 0's {selection passes, selection cycles, sums cycles, groups}
+    if (!h || !out8) return NBLS_ERR_ARG;
     if (!h->d_stamps || h->lts_stamp_waves <= 0) return fail(h, NBLS_ERR_STATE, "developer build with option lts_stamps needed");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<unsigned long long> st((size_t)h->lts_stamp_waves * 8);
     HIPCHK(h, copy_sync(h, st.data(), h->d_stamps + (size_t)h->lts_stamp_waves * 8, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out4[i] = 0.0;
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0;
     for (int64_t g = 0; g < h->lts_stamp_waves; ++g)
-        for (int i = 0; i < 4; ++i) out4[i] += (double)st[(size_t)g * 8 + i];
-    for (int i = 0; i < 4; ++i) out4[i] /= (double)h->lts_stamp_waves;
+        for (int i = 0; i < 8; ++i) out8[i] += (double)st[(size_t)g * 8 + i];
+    for (int i = 0; i < 8; ++i) out8[i] /= (double)h->lts_stamp_waves;
     return NBLS_OK;
 }
 

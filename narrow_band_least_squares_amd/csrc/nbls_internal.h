@@ -22,7 +22,7 @@
 // in a -DNBLS_DEVELOPER build (`make dev`): in-kernel time stamps and ablation switches that make results
 // WRONG on purpose; the shipped library has none of that code in its kernels.
 struct nbls_options {
-    int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 3 generic only where no register kernel exists
+    int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 2 the wave-cooperative kernel for large arrays (round 2); 3 generic only where no register kernel exists
     int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
     int lts_coop_threads = 0;  // > 0: workgroup size of the cooperative LTS kernel
     int verify_global = 0;     // 1: verify candidates from global memory instead of LDS
@@ -155,6 +155,7 @@ struct nbls_handle {
     int32_t* d_starts = nullptr;   // [S][4]
     double* d_rew = nullptr;       // [P+1]
     double* d_xs = nullptr;        // [P][2] standardised co-array
+    double* d_xc = nullptr;        // [P] c0*c1 of the standardised co-array; d_xs and d_xc are padded by 16 pairs (solve_bucket.inc reads one block ahead)
     size_t cap_starts = 0;
 
     // ---- profiling ----

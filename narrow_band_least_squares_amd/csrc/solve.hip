@@ -22,6 +22,8 @@
 #include "nbls_internal.h"
 #include "lts_sortnet.inc"
 #include "wave_ops.h"
+#include "lts_bucket.h"
+#include "lts_bucket_pass.h"
 #include <utility>
 #include <cstdlib>
 
@@ -60,6 +62,7 @@ struct SArgs {
     int u0;                // first unit of this launch (unit batches of the pipelined path)
     unsigned long long* stamps;   // developer (NBLS_LTS_STAMPS=1): 8 s_memtime stamps per wave, else NULL
     int stamp_waves;
+    int stamp_mode;        // developer: 2 = the large-array kernel records every wave's busy cycles instead of thread 0's accounts
 };
 
 __device__ inline double dnan() { return __builtin_nan(""); }
@@ -1729,6 +1732,8 @@ __global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunit
 #endif
 }
 
+#include "solve_bucket.inc"
+
 size_t lts_lds_bytes(int P, int S, bool absr) {
     size_t b = (size_t)(8 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
     b += (size_t)(S + P + NBLS_MAX_CAND + 4) * sizeof(int);
@@ -1823,6 +1828,7 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
             const int64_t cap = (int64_t)(h->cap_stamps / (8 * sizeof(unsigned long long))) / 2;   // second half: the cooperative kernel's C-step breakdown
             a.stamp_waves = (int)(nunits < cap ? nunits : cap);
             h->lts_stamp_waves = a.stamp_waves;
+            a.stamp_mode = h->opt.lts_stamps;
         }
     }
     if (h->opt.lts_impl != 1) {
@@ -1835,8 +1841,29 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
             default: break;
         }
     }
+    if (h->opt.lts_impl == 0 && h->npairs <= NBLS_MAX_PAIRS && a.nstarts <= NBLS_MAX_STARTS && h->d_xc) {
+        // one start per lane, bucket selection (solve_bucket.inc): every other pair count (9..32 elements).
+        // Up to 255 pairs: u8 histogram counters and merging of identical subsets (three 4-wave workgroups per CU at
+        // 120 pairs); beyond: u16 counters and no merging (it removes a tenth of the starts at 496 pairs and its masks
+        // are what would keep a CU at ONE workgroup: two per CU let one unit's refinement run beside the next one's
+        // C-steps).
+        const bool small = h->npairs <= 255;
+        int threads = 256;
+        if (h->opt.lts_coop_threads >= 64 && h->opt.lts_coop_threads <= 512) threads = h->opt.lts_coop_threads & ~63;
+        const size_t bshm = lts_bucket_lds_bytes(h->npairs, a.nstarts, threads / 64, small ? 4 : 2, small);
+        if (bshm <= 160 * 1024) {
+            const void* fn = small ? (const void*)solve_lts_bucket_kernel<4, true> : (const void*)solve_lts_bucket_kernel<2, false>;
+            hipError_t be = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bshm);
+            if (be != hipSuccess) return be;
+            if (small)
+                hipLaunchKernelGGL((solve_lts_bucket_kernel<4, true>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, nunits);
+            else
+                hipLaunchKernelGGL((solve_lts_bucket_kernel<2, false>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, nunits);
+            return hipGetLastError();
+        }
+    }
     if (h->opt.lts_impl != 1 && h->opt.lts_impl != 3) {
-        // wave-cooperative kernel for every other pair count (9..32 elements)
+        // wave-cooperative kernel (lts_impl = 2: the round-2 form, kept for A/B runs)
         const size_t cshm = lts_coop_lds_bytes(h->npairs, a.nstarts);
         if (cshm <= 160 * 1024 && h->npairs <= 512) {
             hipError_t ce = hipFuncSetAttribute((const void*)solve_lts_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);

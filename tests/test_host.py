@@ -207,7 +207,8 @@ def test_hot_kernels_use_no_scratch(tmp_path):
         pytest.skip('no hipcc')
     csrc = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc')
     want = {'xcorr_screen.hip': (['screen_kernel', 'quantize_reg_kernelILi4E', 'verify_lds_kernel', 'verify_dma_kernel'], []),
-            'solve.hip': (['solve_lts_wave_kernelILi28E', 'solve_ols_kernel'], ['-ffp-contract=off'])}
+            'solve.hip': (['solve_lts_wave_kernelILi28E', 'solve_ols_kernel', 'solve_lts_bucket_kernelILi4ELb1E',
+                          'solve_lts_bucket_kernelILi2ELb0E'], ['-ffp-contract=off'])}
     for src, (kernels, flags) in want.items():
         out = tmp_path / (src + '.s')
         subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + csrc, '-S', '--cuda-device-only',
@@ -217,6 +218,20 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             m = re.search(r'\.amdhsa_kernel \S*' + k + r'.*?\.amdhsa_private_segment_fixed_size (\d+)', txt, re.S)
             assert m, k
             assert int(m.group(1)) == 0, '%s spills %s bytes per lane' % (k, m.group(1))
+
+
+def test_bucket_selection_state_machine(tmp_path):
+    """csrc/lts_bucket.h — the per-lane order-statistic state machine of the large-array FAST-LTS kernel (the h-th
+    smallest |r| by bucket refinement, one start per lane) — compiled for the host and checked against a sort on
+    96 000 selections: hostile key sets (exact zeros, heavy ties, keys that differ in their last bits, NaN / Inf,
+    denormals, the whole exponent range), any guess of the threshold, and the high-word bin function against the
+    64-bit one wherever the kernel is allowed to use it."""
+    exe = tmp_path / 'bucket_select_test'
+    subprocess.run(['g++', '-O2', '-std=c++17', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc'),
+                    os.path.join(ROOT, 'tests', 'c_caller', 'bucket_select_test.cpp'), '-o', str(exe)], check=True, timeout=300)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith('ok 96000 ')
 
 
 def test_generated_screen_kloop_is_current():
