@@ -208,7 +208,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
+                    h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_xss, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
@@ -576,6 +576,10 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         }
         if ((rc = alloc_copy(h, &h->d_xs, xs.data(), xs.size()))) return rc;
         if ((rc = alloc_copy(h, &h->d_xc, xc.data(), xc.size()))) return rc;
+        const int NS = (P + 3) / 4;                      // every 4th pair: the sample pass of the large-array LTS kernel
+        std::vector<double> xss((size_t)(NS + 16) * 2, 0.0);
+        for (int i = 0; i < NS; ++i) { xss[2 * i] = xs[2 * (4 * i)]; xss[2 * i + 1] = xs[2 * (4 * i) + 1]; }
+        if ((rc = alloc_copy(h, &h->d_xss, xss.data(), xss.size()))) return rc;
     }
     h->planned = true;
     if (h->opt.plan_timing) {

@@ -72,38 +72,69 @@ __device__ __forceinline__ void bk_load(BkBlk& b, const double* __restrict__ xs,
         }                                                                                      \
     } while (0)
 
-// The same for the sums pass: blocks of 4 pairs with c0, c1, c0*c1 in SGPRs (the squares are one vector multiply
-// each — a table of all three products would not leave room for two blocks in the 100 SGPRs) and y, c0*y, c1*y
-// from LDS.
-struct BkBlkS { double c[8]; double cc[4]; double y[4]; double bx[4]; double by[4]; };
-__device__ __forceinline__ void bk_load_s(BkBlkS& b, const double* __restrict__ xs, const double* __restrict__ xc, const double* y,
-                                          const double* tbx, const double* tby, int k0) {
+// A plain pass over the pairs with the same fetch-ahead structure (the gather pass).
+#define BK_BLOCK8(blk_, kbase_, BODY)                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                         \
+        const double c0 = (blk_).c[2 * j_], c1 = (blk_).c[2 * j_ + 1], yk = (blk_).y[j_];      \
+        BODY                                                                                   \
+    }
+#define BK_FOR_PAIRS8(P_, xs_, y_, BODY)                                                       \
+    do {                                                                                       \
+        const int nb_ = (P_) >> 3;                                                             \
+        BkBlk A_, B_;                                                                          \
+        bk_load(A_, xs_, y_, 0);                                                               \
+        BK_LGKM0();                                                                            \
+        int bi_ = 0;                                                                           \
+        for (; bi_ + 1 < nb_; bi_ += 2) {                                                      \
+            bk_load(B_, xs_, y_, (bi_ + 1) * 8);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            BK_BLOCK8(A_, bi_ * 8, BODY)                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            BK_LGKM0();                                                                        \
+            bk_load(A_, xs_, y_, (bi_ + 2) * 8);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            BK_BLOCK8(B_, (bi_ + 1) * 8, BODY)                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            BK_LGKM0();                                                                        \
+        }                                                                                      \
+        if (bi_ < nb_) { BK_BLOCK8(A_, bi_ * 8, BODY) }                                        \
+        for (int k = nb_ * 8; k < (P_); ++k) {                                                 \
+            const double c0 = (xs_)[2 * k], c1 = (xs_)[2 * k + 1], yk = (y_)[k];               \
+            BODY                                                                               \
+        }                                                                                      \
+    } while (0)
+
+// The same for the sums pass: blocks of 4 pairs with c0, c1, c0*c1 in SGPRs and y from LDS; the other terms of the
+// normal equations (c0^2, c1^2, c0 y, c1 y) are one vector multiply each — tables of them would not leave room for
+// two blocks in the 100 SGPRs, or cost the LDS that a third workgroup per CU needs at 496 pairs.
+struct BkBlkS { double c[8]; double cc[4]; double y[4]; };
+__device__ __forceinline__ void bk_load_s(BkBlkS& b, const double* __restrict__ xs, const double* __restrict__ xc, const double* y, int k0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) b.c[j] = xs[2 * k0 + j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { b.cc[j] = xc[k0 + j]; b.y[j] = y[k0 + j]; b.bx[j] = tbx[k0 + j]; b.by[j] = tby[k0 + j]; }
+    for (int j = 0; j < 4; ++j) { b.cc[j] = xc[k0 + j]; b.y[j] = y[k0 + j]; }
 }
 #define BK_BLOCK4(blk_, kbase_, BODY)                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                         \
         const int k = (kbase_) + j_;                                                           \
         const double c0 = (blk_).c[2 * j_], c1 = (blk_).c[2 * j_ + 1], c01 = (blk_).cc[j_];    \
-        const double yk = (blk_).y[j_], bxk = (blk_).bx[j_], byk = (blk_).by[j_];              \
+        const double yk = (blk_).y[j_];                                                        \
         BODY                                                                                   \
     }
 #define BK_FOR_PAIRS_SUMS(P_, xs_, xc_, L_, BODY)                                              \
     do {                                                                                       \
         const int nb_ = (P_) >> 2;                                                             \
         BkBlkS A_, B_;                                                                         \
-        bk_load_s(A_, xs_, xc_, (L_).y, (L_).tbx, (L_).tby, 0);                                \
+        bk_load_s(A_, xs_, xc_, (L_).y, 0);                                                    \
         BK_LGKM0();                                                                            \
         int bi_ = 0;                                                                           \
         for (; bi_ + 1 < nb_; bi_ += 2) {                                                      \
-            bk_load_s(B_, xs_, xc_, (L_).y, (L_).tbx, (L_).tby, (bi_ + 1) * 4);                \
+            bk_load_s(B_, xs_, xc_, (L_).y, (bi_ + 1) * 4);                                    \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             BK_BLOCK4(A_, bi_ * 4, BODY)                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             BK_LGKM0();                                                                        \
-            bk_load_s(A_, xs_, xc_, (L_).y, (L_).tbx, (L_).tby, (bi_ + 2) * 4);                \
+            bk_load_s(A_, xs_, xc_, (L_).y, (bi_ + 2) * 4);                                    \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             BK_BLOCK4(B_, (bi_ + 1) * 4, BODY)                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -112,7 +143,7 @@ __device__ __forceinline__ void bk_load_s(BkBlkS& b, const double* __restrict__ 
         if (bi_ < nb_) { BK_BLOCK4(A_, bi_ * 4, BODY) }                                        \
         for (int k = nb_ * 4; k < (P_); ++k) {                                                 \
             const double c0 = (xs_)[2 * k], c1 = (xs_)[2 * k + 1], c01 = (xc_)[k];             \
-            const double yk = (L_).y[k], bxk = (L_).tbx[k], byk = (L_).tby[k];                 \
+            const double yk = (L_).y[k];                                                       \
             BODY                                                                               \
         }                                                                                      \
     } while (0)

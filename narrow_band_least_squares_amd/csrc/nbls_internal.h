@@ -155,6 +155,7 @@ struct nbls_handle {
     int32_t* d_starts = nullptr;   // [S][4]
     double* d_rew = nullptr;       // [P+1]
     double* d_xs = nullptr;        // [P][2] standardised co-array
+    double* d_xss = nullptr;       // [ceil(P/4)][2] every 4th row of d_xs (padded likewise)
     double* d_xc = nullptr;        // [P] c0*c1 of the standardised co-array; d_xs and d_xc are padded by 16 pairs (solve_bucket.inc reads one block ahead)
     size_t cap_starts = 0;
 

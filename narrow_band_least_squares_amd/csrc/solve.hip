@@ -1856,9 +1856,9 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
             hipError_t be = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bshm);
             if (be != hipSuccess) return be;
             if (small)
-                hipLaunchKernelGGL((solve_lts_bucket_kernel<4, true>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, nunits);
+                hipLaunchKernelGGL((solve_lts_bucket_kernel<4, true>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, (const double*)h->d_xss, nunits);
             else
-                hipLaunchKernelGGL((solve_lts_bucket_kernel<2, false>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, nunits);
+                hipLaunchKernelGGL((solve_lts_bucket_kernel<2, false>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, (const double*)h->d_xss, nunits);
             return hipGetLastError();
         }
     }

@@ -8,7 +8,7 @@
 #include <cstdio>
 #include "lts_bucket_pass.h"
 
-struct FakeL { const double *y, *tbx, *tby; };
+struct FakeL { const double* y; };
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(const double* __restrict__ xs, const double* __restrict__ xc, const double* yg, int P, int reps,
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(512) void k(const double* __restrict__ xs, const do
         if (MODE == 0) {
             BK_HIST_PASS(P, xs, y, nbls_bucket::bin_of_hw_clamp(lo_hw, sh, hw));
         } else if (MODE == 5) {
-            FakeL L{y, y + (P + 16), y + 2 * (P + 16)};
+            FakeL L{y};
             double obj = 0, sxx = 0, sxy = 0, syy = 0, bx = 0, by = 0;
             unsigned int mw = 0;
             const unsigned long long T = 0x3ff0000000000000ull;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(512) void k(const double* __restrict__ xs, const do
                 sxx = __builtin_fma(c0 * c0, w, sxx);
                 sxy = __builtin_fma(c01, w, sxy);
                 syy = __builtin_fma(c1 * c1, w, syy);
-                bx = __builtin_fma(bxk, w, bx);
-                by = __builtin_fma(byk, w, by);
+                bx = __builtin_fma(c0 * yk, w, bx);
+                by = __builtin_fma(c1 * yk, w, by);
                 mw = (mw << 1) | (unsigned int)in;
                 if ((k & 31) == 31) { hist[lane & 15] = mw; mw = 0u; }
             });
