@@ -223,15 +223,16 @@ def test_hot_kernels_use_no_scratch(tmp_path):
 def test_bucket_selection_state_machine(tmp_path):
     """csrc/lts_bucket.h — the per-lane order-statistic state machine of the large-array FAST-LTS kernel (the h-th
     smallest |r| by bucket refinement, one start per lane) — compiled for the host and checked against a sort on
-    96 000 selections: hostile key sets (exact zeros, heavy ties, keys that differ in their last bits, NaN / Inf,
-    denormals, the whole exponent range), any guess of the threshold, and the high-word bin function against the
-    64-bit one wherever the kernel is allowed to use it."""
+    240 000 selections: hostile key sets (exact zeros, heavy ties, keys that differ in their last bits, NaN / Inf,
+    denormals, the whole exponent range), any guess of the threshold (incl. the kernel's sampled one), gather passes
+    taken at once or after forced extra histogram passes, and the high-word bin function against the 64-bit one
+    wherever the kernel is allowed to use it."""
     exe = tmp_path / 'bucket_select_test'
     subprocess.run(['g++', '-O2', '-std=c++17', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc'),
                     os.path.join(ROOT, 'tests', 'c_caller', 'bucket_select_test.cpp'), '-o', str(exe)], check=True, timeout=300)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.startswith('ok 96000 ')
+    assert r.stdout.startswith('ok 240000 ')
 
 
 def test_generated_screen_kloop_is_current():
