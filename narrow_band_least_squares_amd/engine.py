@@ -459,7 +459,9 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                     mask=mask, lag=lag, cmax=cmax, z=z, sos=[], W=W, inc=inc, pair_idx=None, xij=None,
                     nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs)
 
-    def collect(h, b0, b1):
+    deferred = []                                 # rounds collected before host_overlap has run (sequential rounds)
+
+    def collect(h, b0, b1, notify=True):
         out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
         grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
         mask[b0:b1] = out['mask']
@@ -468,7 +470,9 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
                 if arr is not None:
                     arr[b0:b1] = ext[name]
-        if group_done is not None:
+        if not notify:
+            deferred.append((b0, b1))
+        elif group_done is not None:
             group_done(res, b0, b1)
 
     def finish_skeleton(prep):
@@ -491,7 +495,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             res.sos.extend(prep.sos_ret)
             h = handle if handle is not None else get_handle(device, 0 if sequential else g)
             if sequential and launched:           # one handle, one plan at a time: finish the previous round first
-                collect(*launched.pop())
+                collect(*launched.pop(), notify=False)     # (group_done waits for host_overlap: replayed below)
             early = uploader is not None and g == 0
             # the groups finish in the order they were queued (GPU-side ordering of their correlation stages): the
             # dictionary of group k is built while groups k+1.. are still running.  Left to itself the GPU shares
@@ -507,10 +511,13 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     finally:
         if uploader is not None:                  # prepare() / plan raised: do not leave the copy running behind the caller
             uploader.join()
-    finish_skeleton(prep)
     # everything is queued: host work that needs no GPU result hides behind the passes
+    finish_skeleton(prep)
     if host_overlap is not None:
         host_overlap(res)
+    if group_done is not None:
+        for b0, b1 in deferred:                   # rounds that landed before the skeleton existed, in band order
+            group_done(res, b0, b1)
     for item in launched:
         collect(*item)
     return res

@@ -376,6 +376,27 @@ def test_band_passes_when_hbm_budget_is_small(monkeypatch):
     assert len(split.sos) == len(edges)
 
 
+def test_lts_whole_call_in_several_hbm_rounds(monkeypatch):
+    """ALPHA < 1 with more bands than the filtered-trace budget of one pass: the rounds land inside the
+    launch loop, before the key text exists — tuple, dictionary and key ORDER must equal the one-pass call's."""
+    c = _cfg('cfg2', 0.2)
+    fr = np.logspace(-2, 1, 32)
+    w = np.zeros(32)
+    nb = 7
+    args = (c['WINLEN_list'][:nb], 0.5, 0.5, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1], c['band_type'], fr, 'butter', 2, 0.01)
+    one = narrow_band_least_squares(*args, rij=c['rij'])
+    data = c['data']
+    monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr(3.5 * 8 * data.size / 2.0 ** 30))          # three bands per pass
+    assert engine.max_bands_per_pass(*data.shape) == 3
+    rounds = narrow_band_least_squares(*args, rij=c['rij'])
+    for i in (0, 1, 2, 3, 5, 7, 8):
+        np.testing.assert_array_equal(rounds[i], one[i])
+    assert rounds[6] == one[6] and list(rounds[4].keys()) == list(one[4].keys())
+    assert any(k != 'size' for k in one[4])
+    for k in one[4]:
+        np.testing.assert_array_equal(rounds[4][k], one[4][k])
+
+
 def test_pipelined_band_groups_equal_one_pass(monkeypatch):
     """The whole call cut into 1, 2 and 4 band groups (concurrent passes on several handles of the same GPU,
     dictionary built group by group): identical tuples, identical key order."""

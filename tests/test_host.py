@@ -235,6 +235,54 @@ def test_bucket_selection_state_machine(tmp_path):
     assert r.stdout.startswith('ok 240000 ')
 
 
+def test_sequential_rounds_build_the_dictionary_after_the_skeleton(monkeypatch):
+    """More bands than the HBM budget of one pass, ALPHA < 1 (engine.py): the rounds are collected inside
+    the launch loop, before the result skeleton / key text exist; their dictionary entries must wait for
+    ``host_overlap`` and then appear in band order.  Stand-in handle (no GPU): every window of band b drops pair b."""
+    from narrow_band_least_squares_amd import engine, synthetic
+    from narrow_band_least_squares_amd.narrow_band_least_squares import narrow_band_least_squares
+    c = synthetic.build_config('cfg2', 0.1)
+    nb = 5
+
+    class StubHandle:
+        def set_trace_shape(self, *a): pass
+        def upload_rows(self, rows): pass
+
+    hstub = StubHandle()
+
+    def fake_launch(h, data, prep, **kw):
+        before = kw.get('before_execute')
+        if before is not None:
+            before()
+        P = prep.npairs
+        mask = np.full((prep.nbands, prep.vector_len, prep.mask_bytes), 0xff, dtype=np.uint8)
+        for n in range(prep.nbands):
+            b = fake_launch.next_band + n
+            mask[n, :, (b % P) >> 3] &= np.uint8(~(1 << ((b % P) & 7)) & 0xff)
+        fake_launch.next_band += prep.nbands
+        z = np.zeros((prep.nbands, prep.vector_len))
+        h.out = dict(vel=z + 1.0, baz=z, mdccm=z, sigma_tau=z, mask=mask)
+    fake_launch.next_band = 0
+    hstub.fetch_packed = lambda: hstub.out
+    monkeypatch.setattr(engine, 'launch', fake_launch)
+    monkeypatch.setattr(engine, 'get_handle', lambda device=None, slot=0: hstub)
+    data = c['data']
+    monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr(2.5 * 8 * data.size / 2.0 ** 30))          # two bands per pass
+    assert engine.max_bands_per_pass(*data.shape) == 2
+    fr = np.logspace(-2, 1, 16)
+    w = np.zeros(16)
+    out = narrow_band_least_squares(c['WINLEN_list'][:nb], 0.5, 0.5, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1], 'log',
+                                    fr, 'butter', 2, 0.01, rij=c['rij'])
+    stdict = out[4]
+    keys = [k for k in stdict if k != 'size']
+    assert [k[:2] for k in keys] == sorted(k[:2] for k in keys)                 # band order
+    assert len(keys) == sum(out[6]) and out[7].shape == (nb, 16)
+    pair_idx = np.array([(i, j) for i in range(6) for j in range(i + 1, 6)])
+    for b in range(nb):
+        first = next(k for k in keys if k.startswith('%02d_' % (b + 1)))
+        np.testing.assert_array_equal(np.sort(stdict[first]), np.sort(pair_idx[b % 15] + 1))
+
+
 def test_generated_screen_kloop_is_current():
     """csrc/screen_kloop.inc (the hand-scheduled K loop of the screening kernel) is what its generator prints, and
     its schedule keeps the invariants the kernel relies on: every accumulator is written by exactly the products of
