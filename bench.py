@@ -16,9 +16,12 @@ cache of the host planner is cleared before every step, so no step reuses host w
 
 N = 1: the configuration named by --config (default cfg-3 = BASELINE.json's 8-element metric config; cfg-4 is
 run as ONE GPU's 12-band share of the 96-band / 24 h job, see --band-share).
-N > 1 (one process per GPU, started by ``python -m torch.distributed.run``): --shard bands (default) is ONE
-call of ``narrow_band_least_squares_parallel`` sharded by bands over the ranks with the single RCCL gather
-inside the library (strong scaling: total work fixed); --shard traces gives every rank its own independent
+N > 1: --shard bands (default) is ONE call of ``narrow_band_least_squares_parallel`` sharded by bands over the
+GPUs with the single RCCL gather inside the library (strong scaling: total work fixed) — either one process per GPU
+(started by ``python -m torch.distributed.run``, WORLD_SIZE = N) or, WITHOUT a launcher, ``python bench.py --gpus N``:
+one process that drives GPUs 0..N-1 (``nbls_comm_init_all``).  Fewer than N GPUs visible, or a communicator that
+cannot be formed: one JSON line with ``value`` null and ``status: failed``, exit code 2 — never a silent 1-GPU or
+weak-scaling number under the same metric.  --shard traces (launcher only) gives every rank its own independent
 trace and whole call (weak scaling, no collective).  torch.distributed (gloo) is used by THIS SCRIPT only for
 the barrier around the timed region and the max-over-ranks — the product path has no PyTorch in it.
 
@@ -130,18 +133,43 @@ def main():
     ap.add_argument('--no-noise', action='store_true')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))       # PROCESSES of this job (a launcher's ranks); 1 without a launcher
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    multi = world > 1
+    # Two ways to use N GPUs (dist.py): one process per GPU under a launcher (WORLD_SIZE = N), or — no launcher —
+    # ONE process that drives GPUs 0..N-1 (nbls_comm_init_all, a handle per device): `python bench.py --gpus N`.
+    one_process = world == 1 and args.gpus > 1
+    ngpu = world if world > 1 else max(1, args.gpus)
+    multi = ngpu > 1
     td = None
-    if multi:
+    if world > 1:
         import torch.distributed as td          # barrier + max-over-ranks of this script only
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         td.init_process_group('gloo')
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
-    shard_traces = multi and args.shard == 'traces'
+
+    def give_up(note, code=2):
+        """A run that cannot measure what was asked says so in ONE JSON line (value null) and exits non-zero."""
+        if rank == 0:
+            print(json.dumps({'metric': '(window x band) LTS solves/sec, 8-element synthetic', 'value': None, 'unit': 'solves/s',
+                              'n_gpus': ngpu, 'steps': args.steps, 'warmup': args.warmup, 'status': 'failed', 'note': note}), flush=True)
+        if td is not None:
+            with contextlib.suppress(Exception):
+                td.destroy_process_group()
+        sys.exit(code)
+
+    if one_process:
+        if args.shard == 'traces':
+            give_up('--shard traces needs one process per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py ...)' % ngpu)
+        if os.environ.get('NBLS_DEVICES'):
+            ndev = len([x for x in os.environ['NBLS_DEVICES'].split(',') if x.strip() != ''])
+        else:
+            ndev = len(dist.visible_devices())
+        if ndev < ngpu:
+            give_up('--gpus %d asked, %d GPU(s) visible to this process: not measured' % (ngpu, ndev))
+        os.environ.setdefault('NBLS_DEVICES', ','.join(str(d) for d in range(ngpu)))
+        os.environ['NBLS_DEVICES'] = ','.join(os.environ['NBLS_DEVICES'].split(',')[:ngpu])
+    shard_traces = world > 1 and args.shard == 'traces'
 
     seed = synthetic.SEED + 1 + (rank if shard_traces else 0)
     c = synthetic.build_config(args.config, scale=args.scale, trace_seed=seed)
@@ -216,7 +244,10 @@ def main():
 
     def barrier():
         h.sync()
-        if multi:
+        if one_process:
+            for hd in dist.get_group().handles:
+                hd.sync()
+        if td is not None:
             td.barrier()
 
     def measure_kernels(stream, steps):
@@ -226,7 +257,7 @@ def main():
         my = list(range(nb))
         if multi and not shard_traces:
             npairs_ = nchans * (nchans - 1) // 2
-            my = dist.shard_bands(dist.band_costs(npts, fs_, winlens, c['overlap'], npairs_), world)[rank]
+            my = dist.shard_bands(dist.band_costs(npts, fs_, winlens, c['overlap'], npairs_), ngpu)[rank]
         prep = engine.prepare(nchans, npts, fs_, rij, [edges[b] for b in my], [winlens[b] for b in my], c['overlap'],
                               c['alpha'], c['ftype'], c['order'], c['ripple'])
         h.set_profiling(True)
@@ -254,38 +285,37 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         del held
-        if multi:
+        if td is not None:
             import torch
             tt = torch.tensor([el], dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             el = float(tt.item())
         return el, out
 
-    fallback_note = None
+    # A band-sharded run that cannot form its communicator (or fails in the gather) is NOT replaced by something else
+    # under the same metric: every rank learns of the failure, rank 0 prints a line with value null, exit code 2.
+    failure = None
     try:
         for _ in range(args.warmup):
             one_call(st)
     except Exception as e:      # noqa: BLE001
         if not (multi and not shard_traces):
             raise
-        # the band-sharded call needs the library's RCCL communicator; if that cannot be formed on this node the
-        # bench still reports something useful — every rank its own trace and whole call — and says so
-        fallback_note = 'band-sharded RCCL path failed on rank %d (%s: %s); fell back to --shard traces' % (rank, type(e).__name__, e)
-    if multi:
+        failure = 'band-sharded RCCL path failed on rank %d (%s: %s)' % (rank, type(e).__name__, e)
+    if td is not None:
         import torch
-        flag = torch.tensor([1 if fallback_note else 0])
+        flag = torch.tensor([1 if failure else 0])
         td.all_reduce(flag, op=td.ReduceOp.MAX)
-        if int(flag.item()) and not shard_traces:
-            fallback_note = fallback_note or 'band-sharded RCCL path failed on another rank; fell back to --shard traces'
-            shard_traces = True
-            print(fallback_note, file=sys.stderr)
-            for _ in range(args.warmup):
-                one_call(st)
+        if int(flag.item()) and failure is None:
+            failure = 'band-sharded RCCL path failed on another rank'
+    if failure:
+        print(failure, file=sys.stderr)
+        give_up(failure + '; not measured (no fallback to --shard traces: that is a different, weak-scaling measurement)')
     elapsed, out = timed(st, args.steps)
     kern, stages = measure_kernels(st, max(3, args.steps // 2))
     nwin_list = out[6]
     units_call = int(sum(nwin_list))
-    total_units = units_call * (world if shard_traces else 1)
+    total_units = units_call * (ngpu if shard_traces else 1)
     value = total_units * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
 
@@ -295,7 +325,7 @@ def main():
         Wb = np.array([int(wl * fs) for wl in winlens], dtype=np.float64)
         incb = np.array([int(np.round((1 - c['overlap']) * w)) for w in Wb], dtype=np.float64)
         nw = np.array(nwin_list, dtype=np.float64)
-        units_gpu = units_call if (not multi or shard_traces) else units_call / world
+        units_gpu = units_call if (not multi or shard_traces) else units_call / ngpu
         flop_total = float(np.sum(2.0 * P * Wb * Wb * nw))                    # algorithmic 2 P W^2 per unit
         bytes_total = float(np.sum((8.0 * nchans * incb + 40.0 + math.ceil(P / 8)) * nw))
         mean = lambda k: float(np.mean([s[k] for s in stages]))   # noqa: E731
@@ -306,7 +336,7 @@ def main():
         else:
             kname = 'xcorr_mfma_kernel (f64 MFMA)' if impl_used == 2 else 'xcorr_simple_kernel'
             kern_ms, peak = mean('xcorr_ms'), FP64_MFMA_PEAK_TFLOPS
-        share_f = (1.0 / world) if (multi and not shard_traces) else 1.0      # this rank's part of the call
+        share_f = (1.0 / ngpu) if (multi and not shard_traces) else 1.0       # this rank's part of the call
         achieved_tf = flop_total * share_f / (kern_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -321,7 +351,7 @@ def main():
         launches = int(stages[-1]['xcorr_launches'])
         line = {
             'metric': '(window x band) LTS solves/sec, 8-element synthetic', 'value': value, 'unit': 'solves/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'n_gpus': ngpu, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak' if (shard_traces or not multi) else 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': LABELS.get(args.config, args.config) + ', %s s windows %d%% overlap, %s order %d%s'
@@ -334,11 +364,12 @@ def main():
                        'units_per_call': units_call, 'bands': nb, 'elements': nchans, 'pairs': P,
                        'window_samples': sorted({int(w) for w in Wb}),
                        'parallelism': ('1 GPU' if not multi else
-                                       ('%d GPUs, bands of one call sharded by cost, one RCCL gather in the library' % world
-                                        if not shard_traces else '%d GPUs, one independent trace and whole call per rank, no collective' % world)),
+                                       ('%d GPUs (%s), bands of one call sharded by cost, one RCCL gather in the library'
+                                        % (ngpu, 'one process drives all of them' if one_process else 'one process per GPU')
+                                        if not shard_traces else '%d GPUs, one independent trace and whole call per rank, no collective' % ngpu)),
                        'scale': args.scale},
             'kernel_only_ms': kernel_only,
-            'kernel_only_value': units_gpu / (kernel_only * 1e-3) * (world if multi else 1),
+            'kernel_only_value': units_gpu / (kernel_only * 1e-3) * (ngpu if multi else 1),
             'stage_ms': {'filter': mean('filter_ms'), 'xcorr': mean('xcorr_ms'), 'solve': mean('solve_ms'),
                          'xcorr_quantize': mean('quantize_ms'), 'xcorr_screen': mean('screen_ms'),
                          'xcorr_verify': mean('verify_ms')},
@@ -355,8 +386,6 @@ def main():
                              'note': 'SURVEY 8(d): algorithmic bytes (8*N*inc + 40 + ceil(P/8) per unit) / wall time of the whole call'},
             'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('NBLS_')},
         }
-        if fallback_note:
-            line['note'] = fallback_note
     # what the upload of the trace costs inside a call (host-blocking copy from the stream's buffers)
     rows_up = engine.stream_rows(st)[0]
     t_up = time.perf_counter()
@@ -379,10 +408,10 @@ def main():
                          'xcorr_verify_ms': float(np.mean([s['verify_ms'] for s in stages_n])),
                          'input': 'independent white Gaussian noise on every element, same shape and bands'}
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and ngpu == 1:
             line['cpu_baseline'] = cpu_baseline(c, edges, winlens)
         print(json.dumps(line), flush=True)
-    if multi:
+    if td is not None:
         td.barrier()
         td.destroy_process_group()
 

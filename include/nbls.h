@@ -126,6 +126,9 @@ int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx
  *   lts                         NULL -> ordinary least squares
  *   xcorr_impl                  0 auto, 1 plain VALU kernel, 2 f64-MFMA kernel,
  *                               3 int8-MFMA screening + FP64 verification
+ * May be called while a pass of this handle is still queued (nbls_execute is asynchronous): the table uploads of
+ * the new plan are ordered behind that pass on the GPU, without a host wait.  Fetch that pass's results BEFORE
+ * planning again: the layout nbls_fetch* / nbls_result_layout use is the current plan's.
  */
 int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsections,
               int32_t zero_phase, const double* taper_left, const double* taper_right,
@@ -229,6 +232,11 @@ int nbls_comm_init_rank(nbls_handle* h, const void* id, int32_t world, int32_t r
 int nbls_reserve_results(nbls_handle* h, int64_t bytes);
 int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t block_bytes, int64_t status,
                      void* host_out, int64_t host_bytes);
+/* A rank whose share of the bands does not fit the HBM budget of one pass runs it in several passes
+ * (nbls_plan / nbls_execute / nbls_fetch_packed per round), assembles its block on the host and puts it back where
+ * nbls_comm_gather sends from.  block[nbytes]: the layout of nbls_result_layout for ALL of the rank's bands.
+ * The handle needs a new nbls_plan before its next pass. */
+int nbls_load_result_block(nbls_handle* h, const void* block, int64_t nbytes);
 int nbls_comm_destroy(nbls_handle* h);
 
 /* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects

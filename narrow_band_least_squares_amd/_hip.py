@@ -20,7 +20,7 @@ EXPORTS = [
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
     'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown', 'nbls_filter_segment',
-    'nbls_set_filtered',
+    'nbls_set_filtered', 'nbls_load_result_block',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -80,6 +80,7 @@ def load_library(path=None):
     lib.nbls_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
     lib.nbls_comm_init_rank.argtypes = [vp, C.c_void_p, C.c_int32, C.c_int32]
     lib.nbls_reserve_results.argtypes = [vp, C.c_int64]
+    lib.nbls_load_result_block.argtypes = [vp, C.c_void_p, C.c_int64]
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
     lib.nbls_set_trace_from.argtypes = [vp, vp]
@@ -276,6 +277,12 @@ class Handle:
     def reserve_results(self, nbytes):
         """Minimum allocation of the result block for the next plans (equal-sized gather blocks)."""
         self._chk(self.lib.nbls_reserve_results(self._h, int(nbytes)))
+
+    def load_result_block(self, block):
+        """Put a result block assembled on the host (several HBM rounds of one rank's share) back where the gather
+        sends from.  ``block``: contiguous uint8 array in the layout of ``nbls_result_layout`` for all of the rank's bands."""
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        self._chk(self.lib.nbls_load_result_block(self._h, block.ctypes.data, block.nbytes))
 
     def set_window_ranges(self, first=None, count=None):
         """Per-band window slices for the next plan(s); None resets to "all windows"."""

@@ -77,9 +77,19 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
 //   mpow[j]     = (A^C)^j, j = 0..G        chunk / group transitions
 // Waits for the handle's upload stream when the enclosing API call returns, on every exit path: host tables that
 // alloc_copy queued must have been read by then.
+// On entry the upload stream is made to wait (GPU-side, on this handle's own streams only: other handles' passes
+// are not touched) for whatever pass of THIS handle is still queued: nbls_execute is asynchronous, and the tables a
+// plan overwrites (d_sos, d_fw, d_M, d_unit_*, d_W, d_starts, d_xs, ...) may be under running kernels.
 struct StreamGuard {
     nbls_handle* h;
-    explicit StreamGuard(nbls_handle* hh) : h(hh) {}
+    explicit StreamGuard(nbls_handle* hh) : h(hh) {
+        if (h->up != h->stream && h->ev_plan) {
+            for (hipStream_t s : {h->stream, h->stream2}) {
+                if (!s) continue;
+                if (hipEventRecord(h->ev_plan, s) == hipSuccess) (void)hipStreamWaitEvent(h->up, h->ev_plan, 0);
+            }
+        }
+    }
     ~StreamGuard() { (void)hipStreamSynchronize(h->up); }
 };
 
@@ -196,6 +206,7 @@ int nbls_create(int device_id, nbls_handle** out) {
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) h->num_cus = 0;
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
     if (hipEventCreateWithFlags(&h->ev_xd, hipEventDisableTiming) != hipSuccess) { h->ev_xd = nullptr; (void)hipGetLastError(); }
+    if (hipEventCreateWithFlags(&h->ev_plan, hipEventDisableTiming) != hipSuccess) { h->ev_plan = nullptr; (void)hipGetLastError(); }
     *out = h;
     return NBLS_OK;
 }
@@ -214,6 +225,7 @@ void nbls_destroy(nbls_handle* h) {
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->ev_xd) (void)hipEventDestroy(h->ev_xd);
+    if (h->ev_plan) (void)hipEventDestroy(h->ev_plan);
     if (h->up && h->up != h->stream) (void)hipStreamDestroy(h->up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -759,6 +771,24 @@ int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(out, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, h->stream));   // ordered after the pass
     return finish_pass(h);
+}
+
+int nbls_load_result_block(nbls_handle* h, const void* block, int64_t nbytes) {
+    // the block a rank assembled on the host from several HBM rounds (nbls_fetch_packed per round) goes back into the
+    // handle's result block, where nbls_comm_gather sends from
+    if (!h || !block || nbytes < 0) return NBLS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t need = std::max((size_t)nbytes + 8, h->reserve_res);
+    int rc;
+    if ((rc = ensure(h, &h->d_res, &h->cap_res, need))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_res, 0, h->cap_res, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_res, block, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));              // the host buffer may go away
+    h->res_bytes = (size_t)nbytes;
+    h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = nullptr;   // the views of the last plan no longer describe the block
+    h->d_mask = nullptr;
+    h->planned = false;                                      // ... and a new pass needs a new plan
+    return NBLS_OK;
 }
 
 int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {

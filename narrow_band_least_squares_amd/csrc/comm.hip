@@ -169,6 +169,12 @@ int nbls_reserve_results(nbls_handle* h, int64_t bytes) {
     return NBLS_OK;
 }
 
+// "Nobody hangs": a rank whose local preparation fails (a result block that does not fit block_bytes, a plan made
+// without nbls_reserve_results, a failed allocation of the receive side, a failed HIP call) still ENTERS the
+// collective — with a zeroed stand-in block whose status word is non-zero — and reports its own error afterwards;
+// its peers see the status word instead of blocking in the all-gather.  An RCCL call that fails inside the group
+// is remembered, the group is closed all the same, and the error is returned then.  Only calls that cannot take
+// part at all return early: bad arguments that every rank shares (block_bytes, root), or no communicator.
 int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t block_bytes, int64_t status,
                      void* host_out, int64_t host_bytes) {
     if (!hs || n < 1) return NBLS_ERR_ARG;
@@ -188,61 +194,106 @@ int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t bl
         if (!h->comm || h->comm_world != world) return cfail(h0, NBLS_ERR_STATE, "nbls_comm_gather: no communicator (nbls_comm_init_*)");
         if (root < 0 ? i == 0 : h->comm_rank == root) deliver = h;
     }
+    int first_rc = NBLS_OK;                       // the first local failure: returned AFTER the collective
+    auto note = [&](nbls_handle* h, int code, const std::string& msg) {
+        if (first_rc == NBLS_OK) { first_rc = code; (void)cfail(h, code, msg); if (h != h0) (void)cfail(h0, code, msg); }
+    };
+    auto hipnote = [&](nbls_handle* h, hipError_t e, const char* what) {
+        if (e != hipSuccess) note(h, e == hipErrorOutOfMemory ? NBLS_ERR_NOMEM : NBLS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
     if (deliver && host_out && host_bytes != (int64_t)total)
-        return cfail(h0, NBLS_ERR_ARG, "nbls_comm_gather: host buffer must hold world * block_bytes");
-    // send blocks: the result block padded to block_bytes, last 8 bytes = this rank's status word
+        note(h0, NBLS_ERR_ARG, "nbls_comm_gather: host buffer must hold world * block_bytes");
+    // ---- local preparation: every handle ends up with a send pointer of block_bytes, whatever went wrong ----
+    std::vector<unsigned char*> send(n, nullptr);
+    std::vector<unsigned char*> standin(n, nullptr);          // freed at the end
     for (int i = 0; i < n; ++i) {
         nbls_handle* h = hs[i];
-        HIPC(h, hipSetDevice(h->device));
-        if (h->planned && (int64_t)h->res_bytes + 8 > block_bytes)
-            return cfail(h, NBLS_ERR_ARG, "nbls_comm_gather: block_bytes smaller than the result block + status word");
-        if (!h->d_res || h->cap_res < (size_t)block_bytes) {
-            // a rank that failed before it could plan, or a plan made without nbls_reserve_results
-            if (h->planned) return cfail(h, NBLS_ERR_STATE, "nbls_comm_gather: call nbls_reserve_results(block_bytes) before nbls_plan");
-            if (h->d_res) { (void)hipFree(h->d_res); h->d_res = nullptr; h->cap_res = 0; }
-            HIPC(h, hipMalloc((void**)&h->d_res, (size_t)block_bytes));
-            h->cap_res = (size_t)block_bytes;
-            HIPC(h, hipMemsetAsync(h->d_res, 0, (size_t)block_bytes, h->stream));
+        bool ok = hipnote(h, hipSetDevice(h->device), "hipSetDevice");
+        bool use_own = ok;
+        if (ok && h->planned && (int64_t)h->res_bytes + 8 > block_bytes) {
+            note(h, NBLS_ERR_ARG, "nbls_comm_gather: block_bytes smaller than the result block + status word");
+            use_own = false;
         }
-        h->gather_status = status;
-        HIPC(h, hipMemcpyAsync(h->d_res + block_bytes - 8, &h->gather_status, 8, hipMemcpyHostToDevice, h->stream));
+        if (ok && use_own && (!h->d_res || h->cap_res < (size_t)block_bytes)) {
+            if (h->planned) {
+                note(h, NBLS_ERR_STATE, "nbls_comm_gather: call nbls_reserve_results(block_bytes) before nbls_plan");
+                use_own = false;
+            } else {
+                // a rank that failed before it could plan: an empty block of its own
+                if (h->d_res) { (void)hipFree(h->d_res); h->d_res = nullptr; h->cap_res = 0; }
+                if (hipnote(h, hipMalloc((void**)&h->d_res, (size_t)block_bytes), "hipMalloc(result block)")) {
+                    h->cap_res = (size_t)block_bytes;
+                    (void)hipnote(h, hipMemsetAsync(h->d_res, 0, (size_t)block_bytes, h->stream), "hipMemsetAsync");
+                } else {
+                    h->d_res = nullptr;
+                    use_own = false;
+                }
+            }
+        }
+        if (use_own) {
+            send[i] = h->d_res;
+        } else if (hipMalloc((void**)&standin[i], (size_t)block_bytes) == hipSuccess) {
+            (void)hipMemsetAsync(standin[i], 0, (size_t)block_bytes, h->stream);
+            send[i] = standin[i];
+        } else {
+            (void)hipGetLastError();
+            // nothing to send from: this rank cannot take part (its peers will wait for it)
+            for (int j = 0; j <= i; ++j) if (standin[j]) (void)hipFree(standin[j]);
+            return cfail(h, NBLS_ERR_NOMEM, "nbls_comm_gather: no memory for a " + std::to_string(block_bytes) + "-byte block");
+        }
         const bool recv_side = root < 0 || h->comm_rank == root;
         if (recv_side && (!h->d_gather || h->cap_gather < total)) {
             if (h->d_gather) { (void)hipFree(h->d_gather); h->d_gather = nullptr; h->cap_gather = 0; }
-            HIPC(h, hipMalloc((void**)&h->d_gather, total));
-            h->cap_gather = total;
+            if (hipnote(h, hipMalloc((void**)&h->d_gather, total), "hipMalloc(gather buffer)")) h->cap_gather = total;
+            else {
+                h->d_gather = nullptr;
+                for (int j = 0; j <= i; ++j) if (standin[j]) (void)hipFree(standin[j]);
+                return first_rc;                   // no receive buffer: cannot take part
+            }
         }
     }
-    // ONE grouped operation over all local ranks
-    NCCLC(h0, api, api->GroupStart());
+    // the status word: the caller's, or this process's first failure (every local block carries it)
+    for (int i = 0; i < n; ++i) {
+        nbls_handle* h = hs[i];
+        (void)hipSetDevice(h->device);
+        h->gather_status = first_rc != NBLS_OK ? (int64_t)first_rc : status;
+        (void)hipnote(h, hipMemcpyAsync(send[i] + block_bytes - 8, &h->gather_status, 8, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync(status word)");
+    }
+    // ---- ONE grouped operation over all local ranks; the group is closed whatever happens inside ----
+    auto ncclnote = [&](nbls_handle* h, ncclResult_t r, const char* what) {
+        if (r != ncclSuccess) note(h, NBLS_ERR_COMM, std::string(what) + ": " + api->GetErrorString(r));
+    };
+    ncclnote(h0, api->GroupStart(), "ncclGroupStart");
     for (int i = 0; i < n; ++i) {
         nbls_handle* h = hs[i];
         ncclComm_t c = (ncclComm_t)h->comm;
         if (root < 0) {
-            NCCLC(h, api, api->AllGather(h->d_res, h->d_gather, (size_t)block_bytes, ncclUint8, c, h->stream));
+            ncclnote(h, api->AllGather(send[i], h->d_gather, (size_t)block_bytes, ncclUint8, c, h->stream), "ncclAllGather");
         } else if (h->comm_rank == root) {
             for (int peer = 0; peer < world; ++peer) {
                 if (peer == root) continue;
-                NCCLC(h, api, api->Recv(h->d_gather + (size_t)peer * block_bytes, (size_t)block_bytes, ncclUint8, peer, c, h->stream));
+                ncclnote(h, api->Recv(h->d_gather + (size_t)peer * block_bytes, (size_t)block_bytes, ncclUint8, peer, c, h->stream), "ncclRecv");
             }
         } else {
-            NCCLC(h, api, api->Send(h->d_res, (size_t)block_bytes, ncclUint8, root, c, h->stream));
+            ncclnote(h, api->Send(send[i], (size_t)block_bytes, ncclUint8, root, c, h->stream), "ncclSend");
         }
     }
-    NCCLC(h0, api, api->GroupEnd());
+    ncclnote(h0, api->GroupEnd(), "ncclGroupEnd");
     for (int i = 0; i < n; ++i) {
         nbls_handle* h = hs[i];
-        HIPC(h, hipSetDevice(h->device));
+        (void)hipSetDevice(h->device);
         if (root >= 0 && h->comm_rank == root)      // the root's own block: device-to-device, same stream
-            HIPC(h, hipMemcpyAsync(h->d_gather + (size_t)root * block_bytes, h->d_res, (size_t)block_bytes, hipMemcpyDeviceToDevice, h->stream));
-        if (h == deliver && host_out)
-            HIPC(h, hipMemcpyAsync(host_out, h->d_gather, total, hipMemcpyDeviceToHost, h->stream));
+            (void)hipnote(h, hipMemcpyAsync(h->d_gather + (size_t)root * block_bytes, send[i], (size_t)block_bytes, hipMemcpyDeviceToDevice, h->stream), "hipMemcpyAsync(root block)");
+        if (h == deliver && host_out && host_bytes == (int64_t)total)
+            (void)hipnote(h, hipMemcpyAsync(host_out, h->d_gather, total, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync(gathered blocks)");
     }
     for (int i = 0; i < n; ++i) {
-        HIPC(hs[i], hipSetDevice(hs[i]->device));
-        HIPC(hs[i], hipStreamSynchronize(hs[i]->stream));
+        (void)hipSetDevice(hs[i]->device);
+        (void)hipnote(hs[i], hipStreamSynchronize(hs[i]->stream), "hipStreamSynchronize");
+        if (standin[i]) (void)hipFree(standin[i]);
     }
-    return NBLS_OK;
+    return first_rc;
 }
 
 }  // extern "C"

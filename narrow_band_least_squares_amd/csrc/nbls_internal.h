@@ -54,6 +54,7 @@ struct nbls_handle {
     hipStream_t stream2 = nullptr;  // solve of batch k runs here while batch k+1 is correlated on `stream`
     hipEvent_t ev_xd = nullptr;        // recorded behind the correlation stage of every pass (nbls_execute_after)
     bool ev_xd_recorded = false;
+    hipEvent_t ev_plan = nullptr;      // plan-time uploads wait for this handle's queued kernels (StreamGuard)
     bool ev_xd_by_launcher = false;    // the screening launcher recorded it ahead of its join with the solve stream
     nbls_handle* after = nullptr;      // set for the duration of nbls_execute_after
     int num_cus = 0;                   // compute units of the device (persistent grids)
@@ -145,6 +146,8 @@ struct nbls_handle {
     int32_t* d_cand = nullptr;     // [batch][N][N][16]
     size_t cap_qbuf = 0, cap_qmeta = 0, cap_cand = 0;
     int64_t screen_batch = 0;
+    int skew_n = -1, skew_s = -1;  // partner-image skew of the screening kernel, solved once per (array size, tile shape)
+    int skew_o[32] = {0};
     int64_t lts_stamp_waves = 0;              // developer: waves of the last LTS launch that wrote stamps
     unsigned long long* d_stamps = nullptr;   // developer: s_memtime stamps of the screen kernel's workgroups
     size_t cap_stamps = 0;

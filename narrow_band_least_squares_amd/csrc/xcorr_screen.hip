@@ -1450,19 +1450,20 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     {
         // solved once per array size (cached); a failed/over-budget search falls back to the linear
         // skew o[jj] = jj, which is correct and at most 2-way conflicted
-        static int cache_n = -1;
-        static int cache_o[32];
-        if (cache_n != N) {
+        // (cached in the HANDLE, keyed by array size and tile shape: handles are driven from several host threads
+        //  at once — dist.run_on_handles — and a function-local static would be shared by them)
+        if (h->skew_n != N || h->skew_s != a.S) {
             int o[32] = {0};
             long budget = 200000;
             if (N > 16 || !boff_dfs(o, 0, N, a.S, &budget))
                 for (int q = 0; q < 32; ++q) o[q] = q & 15;   // consecutive partners of a group: distinct slots
-            for (int q = 0; q < 32; ++q) cache_o[q] = o[q];
-            cache_n = N;
+            for (int q = 0; q < 32; ++q) h->skew_o[q] = o[q];
+            h->skew_n = N;
+            h->skew_s = a.S;
         }
         a.boffp0 = a.boffp1 = 0;
-        for (int q = 0; q < 16; ++q) a.boffp0 |= (unsigned long long)(cache_o[q] & 15) << (4 * q);
-        for (int q = 16; q < 32; ++q) a.boffp1 |= (unsigned long long)(cache_o[q] & 15) << (4 * (q - 16));
+        for (int q = 0; q < 16; ++q) a.boffp0 |= (unsigned long long)(h->skew_o[q] & 15) << (4 * q);
+        for (int q = 16; q < 32; ++q) a.boffp1 |= (unsigned long long)(h->skew_o[q] & 15) << (4 * (q - 16));
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     // eight-tile instance: one lag block per tile step and a CU per workgroup (two waves per SIMD: 256 VGPRs)

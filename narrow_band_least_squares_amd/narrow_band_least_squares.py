@@ -224,14 +224,29 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
             raise err[0]
 
     if status == 0:
+        cap = max(1, engine.max_bands_per_pass(nchans, npts))      # filtered bands one pass may keep in HBM
+
         def start(i, hd):
             r = group.ranks[i]
-            if by_windows:
-                engine.launch(hd, rows, prep, window_slice=(r, world), reserve_bytes=block_bytes, trace_ready=True,
-                              before_execute=lambda: landed(i))
-            else:
-                engine.launch(hd, rows, prep, bands=shards[r], reserve_bytes=block_bytes, trace_ready=True,
-                              before_execute=lambda: landed(i))
+            mine = list(range(NBANDS)) if by_windows else shards[r]
+            wsl = (r, world) if by_windows else None
+            if len(mine) <= cap:
+                engine.launch(hd, rows, prep, bands=None if by_windows else mine, window_slice=wsl, reserve_bytes=block_bytes,
+                              trace_ready=True, before_execute=lambda: landed(i))
+                return
+            # the rank's share does not fit the HBM budget of one pass (NBLS_MAX_FILTERED_GB): consecutive passes of
+            # <= cap bands, each fetched to the host; the assembled block goes back to the GPU for the ONE gather
+            MBr = prep.mask_bytes
+            grids = np.zeros((4, len(mine), vector_len))
+            mask = np.zeros((len(mine), vector_len, MBr), dtype=np.uint8)
+            for k0 in range(0, len(mine), cap):
+                sub = mine[k0:k0 + cap]
+                engine.launch(hd, rows, prep, bands=sub, window_slice=wsl, reserve_bytes=block_bytes, trace_ready=True,
+                              before_execute=(lambda: landed(i)) if k0 == 0 else None)
+                out = hd.fetch_packed()
+                grids[:, k0:k0 + len(sub)] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
+                mask[k0:k0 + len(sub)] = out['mask']
+            hd.load_result_block(np.frombuffer(grids.tobytes() + mask.tobytes(), dtype=np.uint8))
         errs = [e for e in dist.run_on_handles(start, group.handles) if e is not None]
         if errs:
             status, failure = 1, errs[0]

@@ -27,15 +27,24 @@ def main():
         assert h.lib.nbls_comm_unique_id(uid, 128) == 0
         h._chk(h.lib.nbls_comm_init_rank(h._h, bytes(uid), 1, 0))
         dist._group_override = dist.Group([h], [0], 1, root=-1)
-    for name, alpha, shard in (('cfg1', 1.0, 'bands'), ('cfg2', 0.5, 'bands'), ('cfg2', 0.75, 'windows')):
+    # (the fourth case: an HBM budget of two bands per pass — the share runs in three rounds, the block assembled on the
+    #  host goes back through nbls_load_result_block and out through the same gather)
+    for name, alpha, shard, per_pass in (('cfg1', 1.0, 'bands', 0), ('cfg2', 0.5, 'bands', 0), ('cfg2', 0.75, 'windows', 0),
+                                         ('cfg2', 0.5, 'bands', 2)):
         os.environ['NBLS_SHARD'] = shard
         c = synthetic.build_config(name, 0.1)
         nb = 5
+        os.environ.pop('NBLS_MAX_FILTERED_GB', None)
+        if per_pass:
+            nchans, npts = c['data'].shape
+            os.environ['NBLS_MAX_FILTERED_GB'] = repr((per_pass + 0.5) * 8.0 * nchans * (npts + 64) / 2.0 ** 30)
+            assert engine.max_bands_per_pass(nchans, npts) == per_pass
         fr = np.logspace(-2, 1, 40)
         w = np.zeros(40)
         args = (c['WINLEN_list'][:nb], 0.5, alpha, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1], c['band_type'],
                 fr, 'butter', 2, 0.01)
         par = narrow_band_least_squares_parallel(*args, rij=c['rij'])
+        os.environ.pop('NBLS_MAX_FILTERED_GB', None)
         ser = narrow_band_least_squares(*args, rij=c['rij'])
         assert par[6] == ser[6]
         for i in (0, 1, 2, 3, 5, 7, 8):

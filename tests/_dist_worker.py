@@ -36,6 +36,20 @@ class FakeHandle:
         assert self.shape is not None and len(rows) == self.shape[0] and all(len(r) == self.shape[1] for r in rows)
         self.uploaded = [np.array(r) for r in rows]
 
+    # several HBM rounds of one rank's share: every round's block is fetched, the assembled one loaded back
+    rounds = 0
+
+    def fetch_packed(self):
+        nb, VL, MB = self.last_shape
+        g = np.frombuffer(self.block[:4 * nb * VL * 8].tobytes(), dtype=np.float64).reshape(4, nb, VL)
+        m = self.block[4 * nb * VL * 8:].reshape(nb, VL, MB)
+        self.rounds += 1
+        return dict(vel=g[0], baz=g[1], mdccm=g[2], sigma_tau=g[3], mask=m)
+
+    def load_result_block(self, block):
+        self.block = np.array(block, dtype=np.uint8)
+        self.loaded = True
+
 
 def make_fake_launch(gold, fail_rank=None, rank_of=None):
     """engine.launch stand-in: the oracle computes the share, the block is left on the fake handle."""
@@ -71,6 +85,7 @@ def make_fake_launch(gold, fail_rank=None, rank_of=None):
         mask = np.packbits(wts, axis=-1, bitorder='little')
         assert mask.shape[-1] == MB
         h.block = np.frombuffer(grids.tobytes() + mask.tobytes(), dtype=np.uint8)
+        h.last_shape = (nb, VL, MB)
         assert reserve_bytes >= len(h.block) + 8
     return fake_launch
 
@@ -141,13 +156,22 @@ def call_and_compare(gold, group, expect_failure=False):
     return nb
 
 
-def run_single_process(gold_name, mode, world, monkeypatch):
+def run_single_process(gold_name, mode, world, monkeypatch, bands_per_pass=None):
+    """``bands_per_pass``: HBM budget (NBLS_MAX_FILTERED_GB) small enough for that many bands per pass, so that the
+    ranks run their shares in several rounds and load the assembled block back before the gather."""
     gold = np.load(os.path.join(ROOT, 'tests', 'golden', gold_name + '.npz'), allow_pickle=False)
     group = LocalGroup(world)
     monkeypatch.setattr(engine, 'launch', make_fake_launch(gold))
     if mode == 'windows':
         monkeypatch.setenv('NBLS_SHARD', 'windows')
-    return call_and_compare(gold, group)
+    if bands_per_pass:
+        nchans, npts = gold['data'].shape
+        monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr((bands_per_pass + 0.5) * 8.0 * nchans * (npts + 64) / 2.0 ** 30))
+        assert engine.max_bands_per_pass(nchans, npts) == bands_per_pass
+    nb = call_and_compare(gold, group)
+    if bands_per_pass:
+        assert any(getattr(h, 'loaded', False) and h.rounds >= 2 for h in group.handles), 'no rank needed several rounds'
+    return nb
 
 
 def main():
@@ -159,7 +183,14 @@ def main():
         os.environ['NBLS_SHARD'] = 'windows'
     gold = np.load(os.path.join(ROOT, 'tests', 'golden', sys.argv[1] + '.npz'), allow_pickle=False)
     engine.launch = make_fake_launch(gold, fail_rank=1 if mode == 'fail' else None, rank_of=lambda h: rank)
-    nb = call_and_compare(gold, GlooGroup(rank, world), expect_failure=(mode == 'fail'))
+    group = GlooGroup(rank, world)
+    if mode == 'fail_early' and rank == 1:
+        # this rank fails BEFORE it can plan (its trace upload cannot even be declared): it must still take part in
+        # the gather, with its status word set, and both ranks must raise
+        def boom(*a):
+            raise RuntimeError('injected failure before planning on rank 1')
+        group.handles[0].set_trace_shape = boom
+    nb = call_and_compare(gold, group, expect_failure=mode in ('fail', 'fail_early'))
     td.barrier()
     if rank == 0:
         print('DIST_OK world=%d bands=%d mode=%s' % (world, nb, mode))

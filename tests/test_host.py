@@ -138,9 +138,19 @@ def test_sharded_path_one_process_many_devices(gold, mode, world, monkeypatch):
     assert _dist_worker.run_single_process(gold, mode, world, monkeypatch) >= 1
 
 
+@pytest.mark.parametrize('gold,mode,world', [('loop_lts_butter_octave', 'bands', 2), ('loop_lts_2octave', 'windows', 2)])
+def test_sharded_path_runs_a_share_in_hbm_rounds(gold, mode, world, monkeypatch):
+    """A rank whose share of the bands exceeds the HBM budget of one pass (the sharded call had lost the
+    rounds of engine.process) runs it in consecutive passes, assembles its block on the host and loads it back for
+    the ONE gather: same tuple as the golden call."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_worker
+    assert _dist_worker.run_single_process(gold, mode, world, monkeypatch, bands_per_pass=1) >= 2
+
+
 @pytest.mark.parametrize('gold,mode', [('loop_ols_butter_linear', 'bands'), ('loop_lts_butter_octave', 'bands'),
                                        ('loop_ols_butter_linear', 'windows'), ('loop_lts_butter_octave', 'windows'),
-                                       ('loop_lts_butter_octave', 'fail')])
+                                       ('loop_lts_butter_octave', 'fail'), ('loop_lts_butter_octave', 'fail_early')])
 def test_band_sharded_path_world_size_2_gloo(gold, mode):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -281,6 +291,19 @@ def test_sequential_rounds_build_the_dictionary_after_the_skeleton(monkeypatch):
     for b in range(nb):
         first = next(k for k in keys if k.startswith('%02d_' % (b + 1)))
         np.testing.assert_array_equal(np.sort(stdict[first]), np.sort(pair_idx[b % 15] + 1))
+
+
+def test_bench_refuses_what_it_cannot_measure():
+    """`python bench.py --gpus N` without a launcher uses the one-process form on GPUs 0..N-1; with fewer GPUs visible
+    (here: none) it must print ONE JSON line with value null / status failed and exit non-zero — never a 1-GPU number
+    under n_gpus N.  Same for --shard traces without a launcher."""
+    import json
+    for extra in (['--gpus', '4'], ['--gpus', '2', '--shard', 'traces']):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'cfg2', '--steps', '1', '--warmup', '0'] + extra,
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, NBLS_DEVICES=''))
+        assert r.returncode == 2, r.stdout + r.stderr
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line['value'] is None and line['status'] == 'failed' and line['n_gpus'] == int(extra[1]) and line['note']
 
 
 def test_generated_screen_kloop_is_current():
