@@ -530,6 +530,55 @@ def test_band_sharded_entry_point_under_rccl(mode):
     assert r.returncode == 0 and 'DIST_GPU_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize('alpha', [0.75, 1.0])
+def test_zero_edit_drop_in_route_with_lat_lon(oracle, tmp_path, alpha):
+    """north_star: "drops into example.py".  tests/_dropin_script.py is written like the reference's script — its import
+    lines verbatim after install_as_reference_modules(), lat/lon LISTS from tr.stats (Vincenty -> co-array on the
+    way to the GPU; every other GPU test passes rij=), the positional PLOT_ARRAY_COORDINATES of the broadband ltsva
+    call, example.py's literal parameters (cheby1, adaptive windows) — and must give the oracle's 9-tuple and
+    broadband 8-tuple for the same lat/lon."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'dropin.npz'
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', '_dropin_script.py'), str(out)],
+                       env=dict(os.environ, DROPIN_ALPHA=repr(alpha)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DROPIN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    g = np.load(out, allow_pickle=False)
+    lat, lon = list(g['lat']), list(g['lon'])
+    st = oracle.make_stream(g['data'], float(g['Fs']), starttime=17884.0729166667, lat=lat, lon=lon)
+    np.testing.assert_allclose(g['rij'], oracle.get_rij(lat, lon, 8), rtol=0, atol=1e-12)
+    # broadband: filter_data -> ltsva with lat/lon
+    stf, fs, sos = oracle.filter_data(st, 'cheby1', 0.1, 5, 2, 0.01)
+    exp = oracle.ltsva(stf, lat, lon, 50, 0.5, alpha, False)
+    for i, k in ((0, 'vel_broad'), (1, 'baz_broad'), (3, 'mdccm_broad')):
+        np.testing.assert_allclose(g[k], exp[i], rtol=RTOL, atol=0, err_msg=k)
+    np.testing.assert_array_equal(g['t_broad'], exp[2])
+    np.testing.assert_allclose(g['sig_tau_broad'], exp[5], rtol=1e-7, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(g['vel_uncert_broad'], exp[6], rtol=1e-5, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(g['baz_uncert_broad'], exp[7], rtol=1e-5, atol=1e-7, equal_nan=True)
+    # narrow band
+    args = (list(g['winlens']), 0.5, alpha, st, lat, lon, 8, g['w_broad'], g['h_broad'], list(g['freqlist']), 'log', g['freq_resp'],
+            'cheby1', 2, 0.01)
+    nb = oracle.narrow_band_least_squares(*args)
+    assert list(g['num_compute']) == nb[6] == [39, 42, 46, 50, 56, 62, 69, 79]
+    for i, k in ((0, 'vel'), (1, 'baz'), (2, 'mdccm')):
+        np.testing.assert_allclose(g[k], nb[i], rtol=RTOL, atol=0, err_msg=k)
+    np.testing.assert_array_equal(g['t'], nb[3])
+    np.testing.assert_allclose(g['sig_tau'], nb[5], rtol=1e-7, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(g['h'], nb[8], rtol=1e-12, atol=1e-300)
+    if alpha < 1.0:
+        for tag, d in (('nb', nb[4]), ('bb', exp[4])):
+            keys = [str(k) for k in g[tag + '_keys']]
+            assert keys == [k for k in d if k != 'size'] and int(g[tag + '_size']) == d['size']
+            off = 0
+            for k, n in zip(keys, g[tag + '_lens']):
+                np.testing.assert_array_equal(g[tag + '_vals'][off:off + n], d[k])
+                off += n
+        assert len(g['nb_keys']) > 0
+
+
 @pytest.mark.parametrize('name', ['loop_ols_cheby1_adaptive', 'loop_ols_butter_linear', 'loop_lts_butter_octave',
                                   'loop_lts_2octave', 'loop_lts_101bands'])
 def test_product_against_reference_loop_goldens(name):
@@ -622,6 +671,81 @@ def test_full_size_cfg3_properties():
     for j, i in enumerate(sub):
         for k in ('vel', 'baz', 'mdccm', 'weights'):
             np.testing.assert_array_equal(getattr(r3, k)[j], getattr(r1, k)[i])
+
+
+def _full_size_properties(c, edges, winlens, nchans_bad, subset, broadband, check_tail_band=None):
+    """Size-independent properties of a production-size pass (no oracle at this size): (i) bit-reproducible;
+    (ii) a band subset reproduces the same rows (what band sharding relies on); (iii) every unit is filled;
+    (iv) the mistimed element is what LTS drops and the plane wave is recovered (a broadband band over the same trace); (v) optionally: the LAST window of band ``check_tail_band`` equals a
+    three-window run over the same filtered samples fed back as a pre-filtered trace — with 12 bands x 16 elements x
+    8.64 M samples the filtered buffer holds 1.66e9 doubles, so this window lies beyond element 2^31 of it."""
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    kw = dict(groups=1)
+    r1 = engine.process(data, fs, t0, c['rij'], edges, winlens, 0.5, 0.5, 'butter', 2, 0.01, **kw)
+    n = r1.nwin.astype(int)
+    tail = None
+    if check_tail_band is not None:
+        b = check_tail_band
+        h = r1.handle
+        filt = h.fetch_filtered(b)                                   # (N, npts) filtered + tapered band, as the device holds it
+        W, inc = int(r1.W[b]), int(r1.inc[b])
+        s0 = (n[b] - 3) * inc
+        tail = np.ascontiguousarray(filt[:, s0:s0 + 2 * inc + W + 1])
+        del filt
+    assert np.all(n > 0)
+    for b in range(len(edges)):
+        assert np.all(r1.mdccm[b, :n[b]] > 0) and np.all(r1.mdccm[b, :n[b]] <= 1.0 + 1e-12)
+        assert np.isfinite(r1.vel[b, :n[b]]).mean() > 0.999
+        assert np.all(r1.weights[b, :n[b]].sum(axis=1) >= r1.weights.shape[2] // 4)      # the reweighting keeps a majority-sized set
+    # the mistimed element is what LTS drops, and the plane wave is recovered: one broadband band over the same trace
+    # (the narrow bands have bandwidth x window length < 5: their correlation peaks are too broad to single it out)
+    rb = engine.process(data, fs, t0, c['rij'], [broadband], [winlens[0]], 0.5, 0.5, 'butter', 2, 0.01, **kw)
+    nbb = int(rb.nwin[0])
+    assert nbb == n.max()
+    assert abs(np.nanmedian(rb.baz[0, :nbb]) - 225.0) < 1.0 and abs(np.nanmedian(rb.vel[0, :nbb]) - 0.34) < 0.01
+    dropped = rb.weights[0, :nbb] == 0
+    bad_pairs = (rb.pair_idx[:, 0] == nchans_bad) | (rb.pair_idx[:, 1] == nchans_bad)
+    assert dropped[:, bad_pairs].mean() > 0.9 and dropped[:, ~bad_pairs].mean() < 0.1
+    r2 = engine.process(data, fs, t0, c['rij'], edges, winlens, 0.5, 0.5, 'butter', 2, 0.01, **kw)
+    for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'weights'):
+        np.testing.assert_array_equal(getattr(r1, k), getattr(r2, k))
+    r3 = engine.process(data, fs, t0, c['rij'], [edges[i] for i in subset], [winlens[i] for i in subset], 0.5, 0.5, 'butter', 2, 0.01,
+                        vector_len=r1.vel.shape[1], **kw)
+    for j, i in enumerate(subset):
+        for k in ('vel', 'baz', 'mdccm', 'weights'):
+            np.testing.assert_array_equal(getattr(r3, k)[j], getattr(r1, k)[i])
+    if tail is not None:
+        b = check_tail_band
+        rt = engine.process(tail, fs, t0, c['rij'], [(None, None)], [winlens[b]], 0.5, 0.5, prefiltered=True)
+        assert int(rt.nwin[0]) == 3
+        last = n[b] - 1
+        for k in ('vel', 'baz', 'mdccm', 'weights', 'sigma_tau'):
+            np.testing.assert_array_equal(getattr(rt, k)[0, 2], getattr(r1, k)[b, last], err_msg=k)
+    return r1
+
+
+def test_full_size_cfg4_share_properties():
+    """BASELINE configs[3] at full size, ONE GPU's share: band share 0 of 8 (12 of the 96 bands, the LPT partition of
+    narrow_band_least_squares_parallel) of the 16-element, 24 h @ 100 Hz trace — 69 096 units, 120 pairs, 500 LCG
+    starts, W = 3000."""
+    from narrow_band_least_squares_amd import dist
+    c = _cfg('cfg4', 1.0)
+    costs = dist.band_costs(c['npts'], c['fs'], list(c['WINLEN_list']), c['overlap'], 120)
+    bands = dist.shard_bands(costs, 8)[0]
+    assert len(bands) == 12
+    edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in bands]
+    winlens = [c['WINLEN_list'][b] for b in bands]
+    r = _full_size_properties(c, edges, winlens, 15, [1, 6, 11], (0.5, 4.0), check_tail_band=11)
+    assert int(r.nwin.sum()) == 69096
+
+
+def test_full_size_cfg5_properties():
+    """BASELINE configs[4] at full size: 32 elements (496 pairs, 500 LCG starts), all 128 bands, 1 h @ 20 Hz — 30 464
+    units in one call (band prefixes beyond '99_' included in the dictionary path elsewhere)."""
+    c = _cfg('cfg5', 1.0)
+    edges = [(c['freqlist'][i], c['freqlist'][i + 1]) for i in range(c['NBANDS'])]
+    r = _full_size_properties(c, edges, list(c['WINLEN_list']), 31, [3, 64, 127], (0.3, 3.0), check_tail_band=127)
+    assert int(r.nwin.sum()) == 30464 and len(edges) == 128
 
 
 def test_full_size_cfg3_band_against_oracle(oracle):
