@@ -76,7 +76,9 @@ typedef struct {
     double screen_ms;         /*   the int8-MFMA screening kernel (dominant kernel)            */
     double verify_ms;         /*   the FP64 verification kernel                                */
     int32_t xcorr_impl;       /* correlator actually used: 1 VALU, 2 f64 MFMA, 3 int8 screening */
-    int32_t reserved;
+    int32_t xcorr_fallback_bands; /* xcorr_impl == 3: bands whose window length does not fit the screening
+                                   * kernel's LDS even with partner groups (> ~7900 samples) and ran on a general
+                                   * correlator; the other bands of the plan were screened                    */
 } nbls_timings;
 
 int nbls_version(void);

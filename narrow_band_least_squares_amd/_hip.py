@@ -46,7 +46,7 @@ class Timings(C.Structure):
     _fields_ = [('filter_ms', C.c_double), ('xcorr_ms', C.c_double), ('solve_ms', C.c_double),
                 ('total_ms', C.c_double), ('xcorr_launches', C.c_int64), ('quantize_ms', C.c_double),
                 ('screen_ms', C.c_double), ('verify_ms', C.c_double), ('xcorr_impl', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('xcorr_fallback_bands', C.c_int32)]
 
 
 _lib = None
@@ -367,7 +367,8 @@ class Handle:
         self._chk(self.lib.nbls_get_timings(self._h, C.byref(t)))
         return dict(filter_ms=t.filter_ms, xcorr_ms=t.xcorr_ms, solve_ms=t.solve_ms,
                     total_ms=t.total_ms, xcorr_launches=t.xcorr_launches, quantize_ms=t.quantize_ms,
-                    screen_ms=t.screen_ms, verify_ms=t.verify_ms, xcorr_impl=t.xcorr_impl)
+                    screen_ms=t.screen_ms, verify_ms=t.verify_ms, xcorr_impl=t.xcorr_impl,
+                    xcorr_fallback_bands=t.xcorr_fallback_bands)
 
     def screen_stamps(self):
         out = np.zeros(10)

@@ -539,19 +539,32 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     h->d_sig = h->d_mdccm + cells;
     h->d_mask = h->d_res + 4 * cells * sizeof(double);
 
-    {   // resolve "auto": int8 screening when the array/window fit it, else f64 MFMA, else plain VALU
-        int S_, PFB_, CSB_, CSA_, WP_, nsl_;
-        size_t lds_;
-        const bool ok = h->d_xij && nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
-        if (xcorr_impl == 3 && !ok)
+    {   // window groups (consecutive bands of one window length) and, per group, whether the int8 screening correlator
+        // applies; "auto" = screening wherever it applies, the faster general correlator elsewhere
+        h->wgroups.clear();
+        int maxWP = 0;
+        bool all_ok = true, any_ok = false;
+        for (int b = 0; b < nbands; ) {
+            int e = b + 1;
+            while (e < nbands && h->W[e] == h->W[b]) ++e;
+            nbls_wgroup g{b, e, h->W[b], h->unit_off[b], h->unit_off[e], false};
+            int S_, PFB_, CSB_, CSA_, WP_, nsl_, G_;
+            size_t lds_;
+            g.screen = h->d_xij && nbls_screen_geometry(h, g.W, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_, &G_);
+            if (g.screen) { any_ok = true; if (WP_ > maxWP) maxWP = WP_; }
+            else if (g.u1 > g.u0) all_ok = false;
+            h->wgroups.push_back(g);
+            b = e;
+        }
+        if (xcorr_impl == 3 && !all_ok)
             return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: the int8 screening correlator needs 3..33 channels and channel images that fit a CU's LDS");
-        if (xcorr_impl == 0 && ok) xcorr_impl = 3;
+        if (xcorr_impl == 0 && any_ok) xcorr_impl = 3;
         h->xcorr_impl = xcorr_impl;
+        if (xcorr_impl != 3) for (nbls_wgroup& g : h->wgroups) g.screen = false;
+        h->screen_wp = maxWP;
     }
     if (xcorr_impl == 3) {
-        int S_, PFB_, CSB_, CSA_, WP_, nsl_;
-        size_t lds_;
-        (void)nbls_screen_geometry(h, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_);
+        const int WP_ = h->screen_wp;
         // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
         const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 96;
         int64_t batch = (int64_t)(batch_mb << 20) / ((int64_t)h->nchans * 2 * WP_);
@@ -568,7 +581,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if ((rc = ensure(h, &h->d_qbuf, &h->cap_qbuf, (size_t)batch * h->nchans * 2 * WP_))) return rc;
         if ((rc = ensure(h, &h->d_qmeta, &h->cap_qmeta, (size_t)batch * h->nchans * (10 + WP_ / 32) * sizeof(double)))) return rc;
         if (h->opt.screen_stamps || h->opt.lts_stamps) {
-            if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * ((h->nchans + 14) / 16) * 8 * sizeof(unsigned long long)))) return rc;   // one record per screening workgroup: (unit, sliding channel, partner group)
+            if ((rc = ensure(h, &h->d_stamps, &h->cap_stamps, (size_t)(batch + 8) * h->nchans * ((h->nchans + 1) / 2) * 8 * sizeof(unsigned long long)))) return rc;   // one record per screening workgroup: (unit, sliding channel, partner group)
         }
         if ((rc = ensure(h, &h->d_cand, &h->cap_cand, (size_t)batch * h->nchans * h->nchans * 32 * sizeof(int32_t)))) return rc;
     }
@@ -798,18 +811,12 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"lts_impl", &nbls_options::lts_impl, false},
         {"lts_generic_h", &nbls_options::lts_generic_h, false},
         {"lts_coop_threads", &nbls_options::lts_coop_threads, false},
-        {"verify_global", &nbls_options::verify_global, false},
-        {"verify_block", &nbls_options::verify_block, false},
-        {"screen_b_dma", &nbls_options::screen_b_dma, false},
-        {"quantize_slab", &nbls_options::quantize_slab, false},
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},
-        {"screen_kold", &nbls_options::screen_kold, false},
         {"screen_tb4", &nbls_options::screen_tb4, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
-        {"filter_store_y1", &nbls_options::filter_store_y1, false},
         {"filter_nomfma", &nbls_options::filter_nomfma, false},
         {"ablate", &nbls_options::ablate, true},
         {"screen_stamps", &nbls_options::screen_stamps, true},
@@ -911,7 +918,7 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int N = h->nchans;
-    const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
+    const int64_t last = h->last_batch > 0 ? h->last_batch : h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
     std::vector<int32_t> c((size_t)last * N * N * 32);
     HIPCHK(h, copy_sync(h, c.data(), h->d_cand, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
@@ -936,7 +943,7 @@ int nbls_debug_screen_stamps(nbls_handle* h, double* out6) {
     if (!h->d_stamps) return fail(h, NBLS_ERR_STATE, "run with NBLS_SCREEN_STAMPS=1");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int64_t last = h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
+    const int64_t last = h->last_batch > 0 ? h->last_batch : h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
     const int64_t nwg = ((last + 7) / 8) * 8 * h->nchans;   // upper bound (one or two channels per workgroup)
     std::vector<unsigned long long> st((size_t)nwg * 8);
     HIPCHK(h, copy_sync(h, st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -489,7 +489,7 @@ hipError_t run_filter(nbls_handle* h) {
     // apply rebuilds each tile's forward output from the raw trace (55 MB shared by all bands: it stays in the
     // caches) before it runs the backward recurrence over it: one 8-byte write per sample instead of two writes
     // and a read.
-    const bool recompute = fuse && h->d_tstate && !h->opt.filter_store_y1;
+    const bool recompute = fuse && h->d_tstate;
     a.tstate = h->d_tstate;
     a.recompute = recompute ? 1 : 0;
     hipError_t e = run_pass<S>(h, a, false);

@@ -22,21 +22,15 @@
 // in a -DNBLS_DEVELOPER build (`make dev`): in-kernel time stamps and ablation switches that make results
 // WRONG on purpose; the shipped library has none of that code in its kernels.
 struct nbls_options {
-    int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 2 the wave-cooperative kernel for large arrays (round 2); 3 generic only where no register kernel exists
+    int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 3 generic only where no register kernel exists
     int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
-    int lts_coop_threads = 0;  // > 0: workgroup size of the cooperative LTS kernel
-    int verify_global = 0;     // 1: verify candidates from global memory instead of LDS
-    int screen_b_dma = 0;      // 1: partner images of the screening kernel staged by LDS-DMA
-    int verify_block = 0;      // 1: block-per-unit LDS verifier instead of the persistent double-buffered one
-    int quantize_slab = 0;     // 1: the LDS-slab quantize kernel for every window length
+    int lts_coop_threads = 0;  // > 0: workgroup size (64..512) of the large-array LTS kernel (solve_bucket.inc)
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
     int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
-    int screen_kold = 0;       // 1: previous K loop of the two-block screening tiles (fragment copies between K steps)
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
     int screen_batch_mb = 96;  // quantised-window bytes per unit batch
     int overlap = 0;           // 1: solve of batch k on a second stream while batch k+1 is correlated
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
-    int filter_store_y1 = 0;   // 1: zero-phase filters write the forward output and read it back (no recompute)
     int filter_nomfma = 0;     // 1: VALU state kernel
     // ---- developer build only ----
     int ablate = 0;            // skip parts of the screening / verify kernels (timing; results wrong)
@@ -46,6 +40,9 @@ struct nbls_options {
     int lts_pad_kb = 0;        // extra LDS per LTS workgroup
     int plan_timing = 0;       // print the host phases of nbls_plan
 };
+
+// Consecutive bands of one window length: the unit of the correlator choice (nbls_plan / nbls_launch_xcorr).
+struct nbls_wgroup { int b0, b1, W; int64_t u0, u1; bool screen; };
 
 struct nbls_handle {
     int device = 0;
@@ -146,6 +143,9 @@ struct nbls_handle {
     int32_t* d_cand = nullptr;     // [batch][N][N][16]
     size_t cap_qbuf = 0, cap_qmeta = 0, cap_cand = 0;
     int64_t screen_batch = 0;
+    int screen_wp = 0;             // padded window length the screening buffers are sized for (largest screened group)
+    int64_t last_batch = 0;        // units of the last screening batch queued (developer statistics)
+    std::vector<nbls_wgroup> wgroups;
     int skew_n = -1, skew_s = -1;  // partner-image skew of the screening kernel, solved once per (array size, tile shape)
     int skew_o[32] = {0};
     int64_t lts_stamp_waves = 0;              // developer: waves of the last LTS launch that wrote stamps
@@ -180,6 +180,7 @@ hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
-bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl);
-hipError_t nbls_launch_xcorr_screen(nbls_handle* h);
+bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G);
+hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int64_t* launches_io);
+hipError_t nbls_xcorr_screen_finish(nbls_handle* h, int64_t launches);
 hipError_t nbls_launch_probe_mfma_i8(nbls_handle* h, const int* da, const int* db, int* dout);

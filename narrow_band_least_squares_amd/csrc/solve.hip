@@ -1154,584 +1154,6 @@ hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t s
     return launch_fast_h<PT, 0>(h, a, nunits, st);
 }
 
-// ------------------------------------------------------------------------------------
-// FAST-LTS for any pair count up to 512 (arrays of 9..32 elements): wave-cooperative selection.
-//
-// The h-subset of a fit needs the h-th smallest of P values per (start, C-step).  With P in the
-// hundreds a lane cannot hold its start's residuals, and counting ranks costs P^2 per lane.  Here the
-// two halves of a C-step run in the layout that suits each:
-//   select  one WAVE per start, lanes across the pairs (k = lane + 64 i): |r_k| as 64-bit keys in
-//           registers (the IEEE bit pattern of a non-negative double orders like the value; NaN sorts
-//           last, as np.argsort does); the h-th smallest key by bitwise bisection, 63 passes of
-//           compare + ballot + popcount; ties at the threshold taken in index order; the subset goes to
-//           LDS as a bit mask (P bits).
-//   sums    one LANE per start: objective and 2x2 normal equations over the masked pairs in ascending
-//           k as fma(t_k, w_k, sum), w in {0,1} -- the arithmetic-order contract of the other kernels
-//           (and of the oracle), so the LTS decisions are identical.
-// One workgroup per unit; every start runs the same number of C-steps in lock step (finished ones are
-// skipped); candidates are then refined with the same two phases.
-// ------------------------------------------------------------------------------------
-struct CoopLds {
-    double *tauv, *y, *X0, *X1, *x0, *x1, *txx, *txy, *tyy, *tbx, *tby, *tmp, *srt;
-    double *objS, *z0S, *z1S, *prevS, *cres;
-    unsigned long long* masks;     // [S][PWS]
-    int *ord, *cand, *misc;
-    unsigned int* tab;             // [1024] one-probe hash of the h-subsets (merging of identical entries)
-    uint8_t *stt, *wsh;
-    int PWS;
-};
-
-__device__ inline CoopLds coop_carve(double* sm, int P, int S) {
-    CoopLds L;
-    L.tauv = sm;          L.y = L.tauv + P;     L.X0 = L.y + P;      L.X1 = L.X0 + P;
-    L.x0 = L.X1 + P;      L.x1 = L.x0 + P;      L.txx = L.x1 + P;    L.txy = L.txx + P;
-    L.tyy = L.txy + P;    L.tbx = L.tyy + P;    L.tby = L.tbx + P;   L.tmp = L.tby + P;
-    L.srt = L.tmp + P;
-    L.objS = L.srt + P;   L.z0S = L.objS + S;   L.z1S = L.z0S + S;   L.prevS = L.z1S + S;
-    L.cres = L.prevS + S;
-    L.PWS = ((P + 63) / 64) | 1;                    // odd row stride: lanes reading their own rows do not collide
-    L.masks = (unsigned long long*)(L.cres + 3 * NBLS_MAX_CAND);
-    L.ord = (int*)(L.masks + (size_t)S * L.PWS);
-    L.cand = L.ord + S;
-    L.misc = L.cand + NBLS_MAX_CAND;
-    L.tab = (unsigned int*)(L.misc + 8);
-    L.stt = (uint8_t*)(L.tab + 1024);
-    L.wsh = L.stt + S;
-    return L;
-}
-
-size_t lts_coop_lds_bytes(int P, int S) {
-    const int PWS = ((P + 63) / 64) | 1;
-    size_t b = (size_t)(13 * P + 4 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
-    b += (size_t)S * PWS * sizeof(unsigned long long);
-    b += (size_t)(S + NBLS_MAX_CAND + 8 + 1024) * sizeof(int);
-    b += (size_t)S + P;
-    return (b + 15) & ~(size_t)15;
-}
-
-// One wave: h-subset of the fit (z0, z1) over the rows (yv, c0, c1)[0..P) -> mask row `out` (PW words).
-// (PWT = ceil(P / 64) is a template parameter: every loop over the lane's keys is unrolled to exactly PWT
-//  steps — with a run-time bound the 8-step loops spent more cycles on scalar tests and branches than on the
-//  ballots: 6 000 cycles per selection at 120 pairs.)
-template <int PWT>
-__device__ inline void coop_select_t(const double* yv, const double* c0, const double* c1, int P, int h,
-                                     double z0, double z1, unsigned long long* out, int lane) {
-
-    unsigned long long key[PWT];
-#pragma unroll
-    for (int i = 0; i < PWT; ++i) {
-        key[i] = ~0ull;                              // beyond P: larger than every candidate threshold
-        const int k = lane + 64 * i;
-        if (k < P)
-            key[i] = (unsigned long long)__double_as_longlong(fabs((yv[k] - c0[k] * z0) - c1[k] * z1));
-    }
-    // h-th smallest key, high word first (31 passes of 32-bit compares); the low word needs its own
-    // bisection only if several keys share the winning high word (rare for residuals)
-    // the high words share their leading bits (sign 0, the top of the exponent): the bisection starts
-    // below the highest bit in which the smallest and the largest differ
-    unsigned int hmin = ~0u, hmax = 0u;
-#pragma unroll
-    for (int i = 0; i < PWT; ++i)
-        if (lane + 64 * i < P) {
-            const unsigned int hw = (unsigned int)(key[i] >> 32);
-            hmin = hw < hmin ? hw : hmin;
-            hmax = hw > hmax ? hw : hmax;
-        }
-    hmin = nbls_wave::min_u32(hmin);
-    hmax = nbls_wave::max_u32(hmax);
-    const unsigned int hdiff = hmin ^ hmax;
-    const int btop = hdiff ? 31 - __builtin_clz(hdiff) : -1;       // wave-uniform
-    unsigned int Thi = btop >= 31 ? 0u : (btop < 0 ? hmin : (hmin & ~((2u << btop) - 1u)));
-    // The bisection also tracks how many keys lie below the current bucket [Thi, Thi + 2^(b+1)) and how many below
-    // its upper end: the bucket always holds the h-th smallest key, and as soon as it holds ONE key that key is the
-    // threshold — the remaining bits need no passes (about half of them at 120..496 pairs).
-    int nbelow = 0, nupto = P;
-    bool single = false;
-    unsigned int bucket_hi = 0u;                     // exclusive upper end of the bucket (high words), when single
-    for (int b = btop > 30 ? 30 : btop; b >= 0; --b) {
-        const unsigned int cnd = Thi | (1u << b);
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < PWT; ++i)
-            cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) < cnd));
-        if (cnt <= h - 1) { Thi = cnd; nbelow = cnt; }   // the h-th smallest high word is >= cnd
-        else nupto = cnt;
-        if (nupto - nbelow == 1) { single = true; bucket_hi = Thi + (1u << b); break; }   // (no overflow: bit b of Thi's bucket base is clear or b < 31)
-    }
-    unsigned int Tlo = 0u;
-    if (single) {
-        // the one key with Thi <= high word < bucket_hi IS the h-th smallest: take it whole
-#pragma unroll
-        for (int i = 0; i < PWT; ++i)
-            {
-                const unsigned int hw = (unsigned int)(key[i] >> 32);
-                const unsigned long long in = __ballot(hw >= Thi && (bucket_hi == 0u || hw < bucket_hi));
-                if (in) {
-                    const int src = __builtin_ctzll(in);
-                    Thi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(key[i] >> 32), src);
-                    Tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[i], src);
-                }
-            }
-    } else {
-    int clt_hi = 0, neq = 0;
-#pragma unroll
-    for (int i = 0; i < PWT; ++i)
-        {
-            clt_hi += __popcll(__ballot((unsigned int)(key[i] >> 32) < Thi));
-            neq += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi));
-        }
-    if (neq == 1) {
-#pragma unroll
-        for (int i = 0; i < PWT; ++i)
-            {
-                const unsigned long long eq = __ballot((unsigned int)(key[i] >> 32) == Thi);
-                if (eq) Tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[i], __builtin_ctzll(eq));
-            }
-    } else {
-        const int h2 = h - clt_hi;                   // rank (1-based) inside the keys that share Thi
-        for (int b = 31; b >= 0; --b) {
-            const unsigned int cnd = Tlo | (1u << b);
-            int cnt = 0;
-#pragma unroll
-            for (int i = 0; i < PWT; ++i)
-                cnt += __popcll(__ballot((unsigned int)(key[i] >> 32) == Thi && (unsigned int)key[i] < cnd));
-            if (cnt <= h2 - 1) Tlo = cnd;
-        }
-    }
-    }
-    const unsigned long long T = ((unsigned long long)Thi << 32) | Tlo;
-    int clt = 0;
-#pragma unroll
-    for (int i = 0; i < PWT; ++i)
-        clt += __popcll(__ballot(key[i] < T));
-    const int m = h - clt;                           // ties at T to take, in index order
-    int prefix = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < PWT; ++i) {
-        {
-            const unsigned long long lt = __ballot(key[i] < T);
-            const unsigned long long tie = __ballot(key[i] == T);
-            const bool take = (key[i] == T) && (prefix + __popcll(tie & below) < m);
-            const unsigned long long mk = lt | __ballot(take);
-            prefix += __popcll(tie);
-            if (lane == 0) out[i] = mk;
-        }
-    }
-}
-
-__device__ inline void coop_select(const double* yv, const double* c0, const double* c1, int P, int h,
-                                   double z0, double z1, unsigned long long* out, int lane) {
-    switch ((P + 63) / 64) {        // wave-uniform
-        case 1: coop_select_t<1>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 2: coop_select_t<2>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 3: coop_select_t<3>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 4: coop_select_t<4>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 5: coop_select_t<5>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 6: coop_select_t<6>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        case 7: coop_select_t<7>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-        default: coop_select_t<8>(yv, c0, c1, P, h, z0, z1, out, lane); break;
-    }
-}
-
-// One lane: objective of (z0, z1) over the masked rows and the LS fit on them (ascending k).
-__device__ inline void coop_sums(const CoopLds& L, const double* yv, const double* c0, const double* c1, int P,
-                                 const unsigned long long* row, double z0, double z1, double* obj_out,
-                                 double* n0, double* n1) {
-    double obj = 0.0, sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
-    for (int w0 = 0; w0 < P; w0 += 64) {
-        const unsigned long long mw = row[w0 >> 6];
-        const int lim = P - w0 < 64 ? P - w0 : 64;
-        for (int q = 0; q < lim; ++q) {
-            const int k = w0 + q;
-            const double w = (double)(unsigned int)((mw >> q) & 1ull);
-            const double r = (yv[k] - c0[k] * z0) - c1[k] * z1;
-            obj = __builtin_fma(r * r, w, obj);
-            sxx = __builtin_fma(L.txx[k], w, sxx);
-            sxy = __builtin_fma(L.txy[k], w, sxy);
-            syy = __builtin_fma(L.tyy[k], w, syy);
-            bx = __builtin_fma(L.tbx[k], w, bx);
-            by = __builtin_fma(L.tby[k], w, by);
-        }
-    }
-    const double det = sxx * syy - sxy * sxy;
-    *obj_out = obj;
-    *n0 = (bx * syy - by * sxy) / det;
-    *n1 = (by * sxx - bx * sxy) / det;
-}
-
-// C-steps in lock step for every live entry (stt == 1): entries are z0S/z1S on entry; on exit finished
-// entries (stt == 2) hold their objective in objS and their z in z0S/z1S.  maxsteps = csteps (starts) or
-// csteps2 (refinement).  Same sequence as the generic kernel: select(z) -> [fit -> select -> obj] * steps.
-__device__ inline void coop_csteps(const CoopLds& L, int P, int S, int h, int maxsteps, bool dedupe, int tid, int nthr,
-                                   unsigned long long* acc = nullptr) {
-    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-#ifdef NBLS_DEVELOPER
-#define COOP_ACC(i, t0) do { if (acc) acc[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#define COOP_NOW() (acc ? __builtin_amdgcn_s_memtime() : 0ull)
-#else
-#define COOP_ACC(i, t0) do { } while (0)
-#define COOP_NOW() 0ull
-    (void)acc;
-#endif
-    for (int it = 0; it <= maxsteps; ++it) {
-        unsigned long long t0 = COOP_NOW();
-        (void)t0;
-        for (int s = wv; s < S; s += nwv)
-            if (L.stt[s] == 1) coop_select(L.y, L.X0, L.X1, P, h, L.z0S[s], L.z1S[s], L.masks + (size_t)s * L.PWS, lane);
-        __syncthreads();
-        COOP_ACC(0, t0);
-        t0 = COOP_NOW();
-        if (dedupe && it < maxsteps) {       // (not in the last iteration: entries that finish there still carry their own z)
-            // entries that landed on the SAME h-subset continue identically from here (a C-step depends
-            // on the subset only): only the lowest start index of each group is carried on, the others
-            // are dropped (they would end with the same (objective, z) and be discarded as duplicate
-            // candidates anyway).  One-probe hash: a collision merely leaves a mergeable entry alive.
-            const int PW = (P + 63) / 64;
-            for (int q = tid; q < 1024; q += nthr) L.tab[q] = 0xffffffffu;
-            __syncthreads();
-            for (int s = tid; s < S; s += nthr) {
-                if (L.stt[s] != 1) continue;
-                const unsigned long long* row = L.masks + (size_t)s * L.PWS;
-                unsigned long long hv = 0x9E3779B97F4A7C15ull;
-                for (int i = 0; i < PW; ++i) hv = (hv ^ row[i]) * 0xD6E8FEB86659FD93ull + (hv >> 29);
-                atomicMin(&L.tab[(unsigned int)(hv >> 40) & 1023u], (unsigned int)s);
-            }
-            __syncthreads();
-            for (int s = tid; s < S; s += nthr) {
-                if (L.stt[s] != 1) continue;
-                const unsigned long long* row = L.masks + (size_t)s * L.PWS;
-                unsigned long long hv = 0x9E3779B97F4A7C15ull;
-                for (int i = 0; i < PW; ++i) hv = (hv ^ row[i]) * 0xD6E8FEB86659FD93ull + (hv >> 29);
-                const unsigned int w = L.tab[(unsigned int)(hv >> 40) & 1023u];
-                if (w != (unsigned int)s) {
-                    const unsigned long long* wr = L.masks + (size_t)w * L.PWS;
-                    bool same = true;
-                    for (int i = 0; i < PW; ++i) same = same && (wr[i] == row[i]);
-                    if (same) L.stt[s] = 4;             // merged into entry w
-                }
-            }
-            __syncthreads();
-        }
-        COOP_ACC(1, t0);
-        t0 = COOP_NOW();
-        int live = 0;
-        int nlive_dbg = 0;
-        for (int s = tid; s < S; s += nthr) {
-            if (L.stt[s] != 1) continue;
-            ++nlive_dbg;
-            double obj, n0, n1;
-            coop_sums(L, L.y, L.X0, L.X1, P, L.masks + (size_t)s * L.PWS, L.z0S[s], L.z1S[s], &obj, &n0, &n1);
-            const int kk = it - 1;                    // index of the C-step whose objective this is
-            if (!(obj == obj)) { L.stt[s] = 0; L.objS[s] = dnan(); continue; }
-            if (it >= 1 && ((kk >= 1 && obj == L.prevS[s]) || kk == maxsteps - 1)) {
-                L.objS[s] = obj;                      // finished: converged, or the last allowed C-step
-                L.stt[s] = 2;
-                continue;
-            }
-            if (it >= 1) L.prevS[s] = obj;
-            L.z0S[s] = n0;
-            L.z1S[s] = n1;
-            live = 1;
-        }
-        (void)nlive_dbg;
-        const int any = __syncthreads_or(live);
-        COOP_ACC(2, t0);
-#ifdef NBLS_DEVELOPER
-        {   // every thread takes part in the barrier; thread 0 (the only one with acc) records
-            const int nl = __syncthreads_count(nlive_dbg);      // live entries of this iteration
-            if (acc) acc[3] += (unsigned long long)nl;
-        }
-#endif
-        if (!any) break;
-    }
-}
-
-__global__ __launch_bounds__(1024) void solve_lts_coop_kernel(SArgs a, int nunits) {
-    extern __shared__ double sm[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int u = a.u0 + blockIdx.x;
-    const int band = a.unit_band[u];
-    const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
-    const int P = a.npairs, S = a.nstarts, h = a.h;
-    const int64_t o = (int64_t)band * a.vector_len + w;
-    const CoopLds L = coop_carve(sm, P, S);
-#ifdef NBLS_DEVELOPER      // phase stamps (same slots as the wave-per-unit kernel: nbls_debug_lts_stamps)
-    unsigned long long* stp = (a.stamps && tid == 0 && (int)blockIdx.x < a.stamp_waves) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
-#define COOP_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define COOP_STAMP(i) do { } while (0)
-#endif
-    COOP_STAMP(0);
-
-    for (int k = tid; k < P; k += nthr) {
-        const double t = (double)a.lag[o * P + k] / a.fs;
-        L.tauv[k] = t;
-        L.tmp[k] = fabs(t);
-        L.X0[k] = a.xs[2 * k];
-        L.X1[k] = a.xs[2 * k + 1];
-        L.x0[k] = a.xij[2 * k];
-        L.x1[k] = a.xij[2 * k + 1];
-        L.wsh[k] = 1;
-    }
-    __syncthreads();
-    // tmad = 1.4826 * median |tau|  (block_sort_small works with any block size <= its stride loop)
-    int m = 0;
-    {
-        if (tid == 0) L.misc[0] = 0;
-        __syncthreads();
-        for (int k = tid; k < P; k += nthr) {
-            const double vk = L.tmp[k];
-            if (vk == vk) {
-                int rank = 0;
-                for (int j = 0; j < P; ++j) { const double vj = L.tmp[j]; rank += (vj < vk) || (vj == vk && j < k); }
-                L.srt[rank] = vk;
-                atomicAdd(&L.misc[0], 1);
-            }
-        }
-        __syncthreads();
-        m = L.misc[0];
-    }
-    const double med = (m & 1) ? L.srt[(m - 1) / 2] : (L.srt[m / 2 - 1] + L.srt[m / 2]) * 0.5;
-    const double tmad = 1.4826 * med;
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) L.tmp[k] = a.cmax[o * P + k];
-    if (tid == 0) L.misc[0] = 0;
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) {
-        const double vk = L.tmp[k];
-        if (vk == vk) {
-            int rank = 0;
-            for (int j = 0; j < P; ++j) { const double vj = L.tmp[j]; rank += (vj < vk) || (vj == vk && j < k); }
-            L.srt[rank] = vk;
-            atomicAdd(&L.misc[0], 1);
-        }
-    }
-    __syncthreads();
-    m = L.misc[0];
-    if (tid == 0) a.mdccm[o] = m == 0 ? dnan() : ((m & 1) ? L.srt[(m - 1) / 2] : (L.srt[m / 2 - 1] + L.srt[m / 2]) * 0.5);
-    __syncthreads();
-    if (tmad == 0.0) {     // "data spike" [R]: not processed
-        if (tid == 0) {
-            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
-            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
-        }
-        for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = 1;
-        return;
-    }
-    for (int k = tid; k < P; k += nthr) {
-        const double yk = L.tauv[k] / tmad;
-        const double c0 = L.X0[k], c1 = L.X1[k];
-        L.y[k] = yk;
-        L.txx[k] = c0 * c0;
-        L.txy[k] = c0 * c1;
-        L.tyy[k] = c1 * c1;
-        L.tbx[k] = c0 * yk;
-        L.tby[k] = c1 * yk;
-    }
-    __syncthreads();
-
-    COOP_STAMP(1);
-    // ---- elemental starts: exact fit on the (up to four) points of the start, ascending index ----
-    for (int s = tid; s < S; s += nthr) {
-        int idx[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) idx[q] = a.starts[4 * s + q];
-        double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
-        // ascending k without a scan over P: repeatedly take the smallest unused index
-        int last = -1;
-        for (int rep = 0; rep < 4; ++rep) {
-            int best = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (idx[q] > last && idx[q] < best) best = idx[q];
-            if (best == 0x7fffffff) break;
-            last = best;
-            sxx = sxx + L.txx[best];
-            sxy = sxy + L.txy[best];
-            syy = syy + L.tyy[best];
-            bx = bx + L.tbx[best];
-            by = by + L.tby[best];
-        }
-        const double det = sxx * syy - sxy * sxy;
-        L.z0S[s] = (bx * syy - by * sxy) / det;
-        L.z1S[s] = (by * sxx - bx * sxy) / det;
-        L.prevS[s] = 0.0;
-        L.objS[s] = dnan();
-        L.stt[s] = 1;
-    }
-    __syncthreads();
-    COOP_STAMP(2);
-#ifdef NBLS_DEVELOPER
-    unsigned long long* acc = stp ? a.stamps + (size_t)(a.stamp_waves + blockIdx.x) * 8 : nullptr;
-    if (acc) for (int i = 0; i < 8; ++i) acc[i] = 0;
-    coop_csteps(L, P, S, h, a.csteps, true, tid, nthr, acc);
-#else
-    coop_csteps(L, P, S, h, a.csteps, true, tid, nthr);
-#endif
-    __syncthreads();
-    COOP_STAMP(3);
-
-    // ---- rank the finished starts by (objective, start index); NaN/inf last ----
-    for (int s = tid; s < S; s += nthr) {
-        const double os = L.stt[s] == 2 ? L.objS[s] : dnan();
-        const bool fs_ = (os == os) && os < __builtin_inf();
-        int rank = 0;
-        for (int t = 0; t < S; ++t) {
-            const double ot = L.stt[t] == 2 ? L.objS[t] : dnan();
-            const bool ft = (ot == ot) && ot < __builtin_inf();
-            bool before;
-            if (ft && fs_) before = (ot < os) || (ot == os && t < s);
-            else if (ft && !fs_) before = true;
-            else if (!ft && fs_) before = false;
-            else before = t < s;
-            rank += before;
-        }
-        L.ord[rank] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int nc = 0;
-        for (int r = 0; r < S && nc < a.ncand; ++r) {
-            const int s = L.ord[r];
-            if (L.stt[s] != 2) break;
-            const double os = L.objS[s];
-            if (!((os == os) && os < __builtin_inf())) break;
-            bool dup = false;
-            for (int c = 0; c < nc; ++c) {
-                const int cs = L.cand[c];
-                if (L.objS[cs] == os && L.z0S[cs] == L.z0S[s] && L.z1S[cs] == L.z1S[s]) { dup = true; break; }
-            }
-            if (!dup) L.cand[nc++] = s;
-        }
-        L.misc[1] = nc;
-    }
-    __syncthreads();
-    const int nc = L.misc[1];
-    // ---- refine the candidates to convergence: only they stay live ----
-    for (int s = tid; s < S; s += nthr) {
-        bool is_c = false;
-        for (int c = 0; c < nc; ++c) is_c = is_c || (L.cand[c] == s);
-        L.stt[s] = is_c ? 1 : 3;
-        if (is_c) L.prevS[s] = 0.0;
-    }
-    __syncthreads();
-    COOP_STAMP(4);
-    coop_csteps(L, P, S, h, a.csteps2, false, tid, nthr);
-    __syncthreads();
-    COOP_STAMP(5);
-    // ---- best candidate -> de-standardise ----
-    double zr0 = dnan(), zr1 = dnan();
-    {
-        double best = __builtin_inf();
-        for (int c = 0; c < nc; ++c) {
-            const int s = L.cand[c];
-            const double ob = L.stt[s] == 2 ? L.objS[s] : dnan();
-            if (ob < best) { best = ob; zr0 = L.z0S[s]; zr1 = L.z1S[s]; }
-        }
-        zr0 = zr0 * tmad / a.xmad0;
-        zr1 = zr1 * tmad / a.xmad1;
-    }
-    const bool finite_z = (zr0 - zr0 == 0.0) && (zr1 - zr1 == 0.0);
-    if (!finite_z) {
-        if (tid == 0) {
-            a.vel[o] = dnan(); a.baz[o] = dnan(); a.sig[o] = dnan();
-            a.z[2 * o] = dnan(); a.z[2 * o + 1] = dnan();
-        }
-        for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = 1;
-        return;
-    }
-    // ---- raw scale from the h smallest residuals in original units (wave 0 selects, thread 0 sums) ----
-    __syncthreads();
-    if (wv == 0) coop_select(L.tauv, L.x0, L.x1, P, h, zr0, zr1, L.masks, lane);
-    for (int k = tid; k < P; k += nthr) {
-        // product tables in original units (the standardised ones are no longer needed)
-        const double c0 = L.x0[k], c1 = L.x1[k], tk = L.tauv[k];
-        L.txx[k] = c0 * c0;
-        L.txy[k] = c0 * c1;
-        L.tyy[k] = c1 * c1;
-        L.tbx[k] = c0 * tk;
-        L.tby[k] = c1 * tk;
-        L.tmp[k] = (tk - c0 * zr0) - c1 * zr1;       // residual of the raw fit
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double ssq = 0.0;
-        for (int k = 0; k < P; ++k) {
-            const double wk = (double)(unsigned int)((L.masks[k >> 6] >> (k & 63)) & 1ull);
-            ssq = __builtin_fma(L.tmp[k] * L.tmp[k], wk, ssq);
-        }
-        L.cres[0] = sqrt(ssq / (double)h) * a.raw_factor;
-    }
-    __syncthreads();
-    const double s0 = L.cres[0];
-    const bool tiny = fabs(s0) < a.zero_scale;
-    for (int k = tid; k < P; k += nthr)
-        L.wsh[k] = tiny ? (fabs(L.tmp[k]) < a.zero_scale) : (fabs(L.tmp[k] / s0) <= a.quantile);
-    __syncthreads();
-    if (tid == 0) {
-        double zf0 = zr0, zf1 = zr1;
-        if (!tiny) {
-            int nw = 0;
-            double sxx = 0.0, sxy = 0.0, syy = 0.0, bx = 0.0, by = 0.0;
-            for (int k = 0; k < P; ++k) {
-                const double wk = (double)L.wsh[k];
-                nw += L.wsh[k];
-                sxx = __builtin_fma(L.txx[k], wk, sxx);
-                sxy = __builtin_fma(L.txy[k], wk, sxy);
-                syy = __builtin_fma(L.tyy[k], wk, syy);
-                bx = __builtin_fma(L.tbx[k], wk, bx);
-                by = __builtin_fma(L.tby[k], wk, by);
-            }
-            const double det = sxx * syy - sxy * sxy;
-            zf0 = (bx * syy - by * sxy) / det;
-            zf1 = (by * sxx - bx * sxy) / det;
-            L.misc[2] = nw;
-        }
-        L.cres[1] = zf0;
-        L.cres[2] = zf1;
-    }
-    __syncthreads();
-    const double zf0 = L.cres[1], zf1 = L.cres[2];
-    for (int k = tid; k < P; k += nthr) L.tmp[k] = (L.tauv[k] - L.x0[k] * zf0) - L.x1[k] * zf1;
-    __syncthreads();
-    if (!tiny) {
-        if (tid == 0) {
-            const int nw = L.misc[2];
-            double ssw = 0.0;
-            for (int k = 0; k < P; ++k) ssw = __builtin_fma(L.tmp[k] * L.tmp[k], (double)L.wsh[k], ssw);
-            L.cres[3] = nw > 1 ? sqrt(ssw / (double)(nw - 1)) * a.rew[nw] : 0.0;
-        }
-        __syncthreads();
-        const double scale = L.cres[3];
-        if (scale > 0.0)
-            for (int k = tid; k < P; k += nthr) L.wsh[k] = fabs(L.tmp[k] / scale) <= a.quantile;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        int nw = 0;
-        double acc = 0.0;
-        for (int k = 0; k < P; ++k) {
-            nw += L.wsh[k];
-            acc = __builtin_fma(L.tauv[k] * L.tmp[k], (double)L.wsh[k], acc);
-        }
-        double vel, baz;
-        vel_baz(zf0, zf1, &vel, &baz);
-        a.vel[o] = vel;
-        a.baz[o] = baz;
-        a.sig[o] = nw > 2 ? sqrt(acc / (double)(nw - 2)) : dnan();
-        a.z[2 * o] = zf0;
-        a.z[2 * o + 1] = zf1;
-    }
-    __syncthreads();
-    for (int k = tid; k < P; k += nthr) a.wts[o * P + k] = L.wsh[k];
-    COOP_STAMP(6);
-#ifdef NBLS_DEVELOPER
-    if (stp) stp[7] = (unsigned long long)nc;
-#endif
-}
-
 #include "solve_bucket.inc"
 
 size_t lts_lds_bytes(int P, int S, bool absr) {
@@ -1859,19 +1281,6 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
                 hipLaunchKernelGGL((solve_lts_bucket_kernel<4, true>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, (const double*)h->d_xss, nunits);
             else
                 hipLaunchKernelGGL((solve_lts_bucket_kernel<2, false>), dim3(nunits), dim3(threads), bshm, st, a, (const double*)h->d_xs, (const double*)h->d_xc, (const double*)h->d_xss, nunits);
-            return hipGetLastError();
-        }
-    }
-    if (h->opt.lts_impl != 1 && h->opt.lts_impl != 3) {
-        // wave-cooperative kernel (lts_impl = 2: the round-2 form, kept for A/B runs)
-        const size_t cshm = lts_coop_lds_bytes(h->npairs, a.nstarts);
-        if (cshm <= 160 * 1024 && h->npairs <= 512) {
-            hipError_t ce = hipFuncSetAttribute((const void*)solve_lts_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
-            if (ce != hipSuccess) return ce;
-            int threads = a.nstarts > 256 ? 512 : 256;
-            if (cshm > 80 * 1024 && a.nstarts > 512 - 64) threads = 1024;    // one workgroup per CU anyway: give it all four wave slots per SIMD
-            if (h->opt.lts_coop_threads >= 64) threads = h->opt.lts_coop_threads;
-            hipLaunchKernelGGL(solve_lts_coop_kernel, dim3(nunits), dim3(threads), cshm, st, a, nunits);
             return hipGetLastError();
         }
     }

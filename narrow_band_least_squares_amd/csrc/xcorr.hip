@@ -35,6 +35,7 @@ struct XArgs {
     int S;                    // lag blocks (of 16) per tile = floor(16 / (N-1))
     int CS;                   // LDS elements per channel buffer, == 2 (mod 32)
     int PF;                   // zero padding in front of each channel window
+    int u0;                   // first unit of this launch (window groups of a plan: nbls_launch_xcorr)
 };
 
 __device__ inline bool better(double v1, int k1, double v2, int k2) {
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    const int u = (int)(bid / a.npairs);
+    const int u = a.u0 + (int)(bid / a.npairs);
     const int k = (int)(bid % a.npairs);
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
     const int lane = tid & 63;
     const int wv = tid >> 6;                    // sliding channel of this wave
     const int N = a.nchans;
-    const int u = blockIdx.x;
+    const int u = a.u0 + blockIdx.x;
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int W = a.Wb[band];
@@ -273,7 +274,9 @@ __global__ void probe_mfma_f64_kernel(const double* a, const double* b, double* 
 
 }  // namespace
 
-hipError_t nbls_launch_xcorr(nbls_handle* h) {
+// The general correlators for the units [ub, ue) (windows of up to gW samples).  impl: 1 plain VALU, 2 f64 MFMA,
+// 0 the faster one that applies.
+static hipError_t launch_general_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int impl, int* used) {
     XArgs a;
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
@@ -288,9 +291,9 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     a.vector_len = h->vector_len;
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
-    if (h->nunits == 0) return hipSuccess;
-    if (h->xcorr_impl == 3) { h->xcorr_impl_used = 3; return nbls_launch_xcorr_screen(h); }   // int8 screening + FP64 verification
-    h->tim.xcorr_launches = 1;
+    a.u0 = (int)ub;
+    const int64_t nu = ue - ub;
+    if (nu <= 0) return hipSuccess;
     // f64-MFMA kernel: needs one wave per channel (N <= 16) and the N-channel window in LDS
     const int N = h->nchans;
     bool mfma_ok = N >= 3 && N <= 16 && h->npairs <= 64 * N;
@@ -298,29 +301,66 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
     if (mfma_ok) {
         a.S = 16 / (N - 1);
         a.PF = 16 * (a.S - 1);
-        int cs = a.PF + h->maxW + 32;
+        int cs = a.PF + gW + 32;
         cs += ((2 - cs) % 32 + 32) % 32;            // CS == 2 (mod 32)
         a.CS = cs;
         shm_m = ((size_t)N * cs + N + N * 16) * sizeof(double) + (size_t)N * 16 * sizeof(int);
         if (shm_m > 160 * 1024) mfma_ok = false;
     }
-    if (h->xcorr_impl == 2 && !mfma_ok) return hipErrorInvalidValue;
-    if (mfma_ok && h->xcorr_impl != 1) {
+    if (impl == 2 && !mfma_ok) return hipErrorInvalidValue;
+    if (mfma_ok && impl != 1) {
         hipError_t e = hipFuncSetAttribute((const void*)xcorr_mfma_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m);
         if (e != hipSuccess) return e;
-        h->xcorr_impl_used = 2;
-        hipLaunchKernelGGL(xcorr_mfma_kernel, dim3((unsigned)h->nunits), dim3(64 * N), shm_m, h->stream, a);
+        *used = 2;
+        hipLaunchKernelGGL(xcorr_mfma_kernel, dim3((unsigned)nu), dim3(64 * N), shm_m, h->stream, a);
         return hipGetLastError();
     }
-    const int64_t nblocks = h->nunits * h->npairs;
-    const size_t shm = (size_t)2 * h->maxW * sizeof(double);
+    const int64_t nblocks = nu * h->npairs;
+    const size_t shm = (size_t)2 * gW * sizeof(double);
     if (shm > 48 * 1024) {      // long windows (W up to 10000): opt in to more than the default dynamic LDS
         hipError_t e = hipFuncSetAttribute((const void*)xcorr_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    h->xcorr_impl_used = 1;
+    *used = 1;
     hipLaunchKernelGGL(xcorr_simple_kernel, dim3((unsigned)nblocks), dim3(256), shm, h->stream, a);
+    return hipGetLastError();
+}
+
+// The correlation stage of a pass.  The plan's bands come in window groups (h->wgroups: consecutive bands of one
+// window length): each group takes the int8 screening path when its channel images fit a CU's LDS (possibly with
+// partner groups) and a general correlator otherwise — a long-window band of an adaptive-window plan no longer sends
+// every band of the plan to the 50x slower kernel.
+hipError_t nbls_launch_xcorr(nbls_handle* h) {
+    if (h->nunits == 0) return hipSuccess;
+    h->tim.xcorr_launches = 0;
+    h->tim.xcorr_fallback_bands = 0;
+    h->bev_used = 0;
+    int64_t launches = 0;
+    int used = 0, fallback_bands = 0;
+    bool any_screen = false;
+    for (const nbls_wgroup& g : h->wgroups) {
+        if (g.u1 <= g.u0) continue;
+        hipError_t e;
+        if (h->xcorr_impl == 3 && g.screen) {
+            any_screen = true;
+            e = nbls_launch_xcorr_screen_range(h, g.u0, g.u1, g.W, &launches);
+        } else {
+            int u_ = 0;
+            e = launch_general_range(h, g.u0, g.u1, g.W, h->xcorr_impl == 3 ? 0 : h->xcorr_impl, &u_);
+            used = u_ > used ? u_ : used;
+            fallback_bands += g.b1 - g.b0;
+            if (h->xcorr_impl != 3) ++launches;
+        }
+        if (e != hipSuccess) return e;
+    }
+    if (h->xcorr_impl == 3 && any_screen) {
+        h->xcorr_impl_used = 3;
+        h->tim.xcorr_fallback_bands = fallback_bands;          // bands of this pass that ran on a general correlator
+        return nbls_xcorr_screen_finish(h, launches);
+    }
+    h->xcorr_impl_used = used;
+    h->tim.xcorr_launches = launches;
     return hipGetLastError();
 }
 

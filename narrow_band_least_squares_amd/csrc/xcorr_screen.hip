@@ -64,12 +64,11 @@ struct QArgs {
     // screen
     int S, PFB, CSB, CSA;
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
-    int npg;                  // partner groups per sliding channel (1 up to 17 elements)
+    int npg;                  // partner groups per sliding channel (1: all partners in one workgroup)
+    int pgsz;                 // partners per group (<= 16; fewer when the images of all partners do not fit a CU's LDS)
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
-    int b_dma;                // partner images staged by LDS-DMA
     unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
-    int kold;                 // previous form of the two-block K loop (fragment copies between K steps)
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
     unsigned long long boffp0, boffp1;   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
                               // packed so that a per-lane lookup is a select and a shift, not a load from the argument block
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     const int N = a.nchans;
     const int NSL = a.nsl;
     const int NCP = (N + NSL - 1) >> (NSL - 1);      // channel pairs (or single channels) per unit (NSL is 1 or 2)
-    const int NPG = a.npg;                           // partner groups of <= 16 partners (arrays of > 17 elements)
+    const int NPG = a.npg;                           // partner groups of <= a.pgsz partners (arrays of > 17 elements, long windows)
     // keep the workgroups of one unit on one XCD (the linear block index % 8 says which blocks share an XCD; the
     // grid is 8*NCP*NPG wide, so that is blockIdx.x % 8) so that the unit's quantised window is fetched into that
     // XCD's L2 once.  Speed only.  Grid rows = groups of eight units: no integer division by run-time values here
@@ -440,8 +439,8 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     // wave-uniform (keeps the K loop scalar); with one window length for all bands no load is needed
     const int W = a.Wuni ? a.Wuni : __builtin_amdgcn_readfirstlane(a.Wb[__builtin_amdgcn_readfirstlane(a.unit_band[u])]);
     const int S = a.S, PFB = a.PFB, CSB = a.CSB, CSA = a.CSA, WP = a.WP;
-    const int pgbase = 16 * pg;                      // first partner index of this workgroup's group
-    const int NP = (N - 1 - pgbase) < 16 ? (N - 1 - pgbase) : 16;   // partners handled here
+    const int pgbase = a.pgsz * pg;                  // first partner index of this workgroup's group
+    const int NP = (N - 1 - pgbase) < a.pgsz ? (N - 1 - pgbase) : a.pgsz;   // partners handled here
 
     // LDS: channel images [N][2 limbs][CSB] (channel j skewed by boff[j] sixteen-byte slots so that the
     // B-fragment reads are bank-conflict free for every sliding channel), then per sliding channel the
@@ -527,26 +526,6 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
         tab_b = m[tab_k];
         if (tab_row < NSL) tab_a = m[NB];
     }
-    if (stage_on && a.b_dma) {
-        // partner images by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction straight into LDS, no
-        // registers, no ds_write); the zero padding in front of and behind the samples is written by hand
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        const int gfirst = PFB / 16, gvalid = WP / 16;                  // groups [gfirst, gfirst + gvalid) carry samples
-        for (int row = wv; row < nrowB; row += nwaves) {
-            const int slot = row >> 1, limb = row & 1;
-            const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
-            const int8_t* src = a.qbuf + (((int64_t)ul * N + ch) * 2 + limb) * WP;
-            unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * boff_of(a, ch);
-            for (int g0 = 0; g0 < gvalid; g0 += 64) {
-                const int g = g0 + lane;
-                if (g < gvalid)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src + g * 16), (lptr_t)(dst + (size_t)(gfirst + g0) * 16), 16, 0, 0);
-            }
-            for (int g = lane; g < gB; g += 64)
-                if (g < gfirst || g >= gfirst + gvalid) *(uint4*)(dst + g * 16) = make_uint4(0, 0, 0, 0);
-        }
-    } else
     if (stage_on)
     for (int row0 = wv; row0 < nrowB; row0 += 2 * nwaves) {
         for (int g0 = lane; g0 < gB; g0 += 256) {
@@ -822,7 +801,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
         if (!(NBLS_ABL(1))) {
         // the partner fragments of the NEXT K step are fetched while this step's products run
         v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
-        if (step == 32 && !a.kold) {
+        if (step == 32) {
             // Two lag blocks per tile step (5..8 partners): hand-scheduled K loop, see screen_kloop.inc (generated by
             // tools/gen_screen_kloop.py).  Tile t+2 at K step n and tile t at K step n+1 read the SAME A fragment, so
             // the A stream is walked once and every fragment pair is multiplied by two partner fragments; nothing is
@@ -842,40 +821,6 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
 #ifdef NBLS_DEVELOPER
             dev_kcyc += __builtin_amdgcn_s_memtime() - kt0; dev_ksteps += nst;
 #endif
-        } else if (step == 32) {
-            // (previous form of the loop, option screen_kold: the A fragments of tiles 2,3 are copied into the
-            // registers of tiles 0,1 after every K step)
-            // two lag blocks per tile step (7 partners, the 8-element array): tiles t+2 and t are 64
-            // bytes = one K step apart, so the A fragments of tiles 2,3 are next iteration's tiles 0,1
-            // and only half of the A fragments are read from LDS per K step
-            v4i a0h = ld_frag64(qa_h), a0l = ld_frag64(qa_l);
-            v4i a1h = ld_frag64(qa_h + 32), a1l = ld_frag64(qa_l + 32);
-            for (int n0 = 0; n0 < klen; n0 += 64) {
-                const int nn = n0 + 64 < klen ? n0 + 64 : n0;       // (the last step re-reads its own)
-                const v4i bhn = *(const v4i*)(pBh + nn);
-                const v4i bln = *(const v4i*)(pBl + nn);
-                const v4i a2h = ld_frag64(qa_h + n0 + 64);
-                const v4i a2l = ld_frag64(qa_l + n0 + 64);
-                const v4i a3h = ld_frag64(qa_h + n0 + 96);
-                const v4i a3l = ld_frag64(qa_l + n0 + 96);
-                // keep the order: all LDS reads first, then the six products of the fragments already in
-                // registers (their 96 matrix-pipe cycles cover the LDS latency), then the six of the new ones.
-                // (Unrolling by two with swapped roles removes the register copies below but pushes the
-                // kernel over 128 VGPRs: 100 B of scratch per lane = 1 GB of spill traffic per launch.)
-                __builtin_amdgcn_sched_barrier(0);
-                TILE_H(a0h, h0, m0);
-                TILE_H(a1h, h1, m1);
-                TILE_L(a0l, m0);
-                TILE_L(a1l, m1);
-                __builtin_amdgcn_sched_barrier(0);
-                TILE_H(a2h, h2, m2);
-                TILE_H(a3h, h3, m3);
-                TILE_L(a2l, m2);
-                TILE_L(a3l, m3);
-                __builtin_amdgcn_sched_barrier(0);
-                a0h = a2h; a0l = a2l; a1h = a3h; a1l = a3l;
-                bh = bhn; bl = bln;
-            }
         } else
         for (int n0 = 0; n0 < klen; n0 += 64) {
             const int nn = n0 + 64 < klen ? n0 + 64 : n0;
@@ -1374,42 +1319,54 @@ static bool boff_dfs(int* o, int j, int N, int S, long* budget) {
     return false;
 }
 
-// Eligibility + LDS size of the screening path.
-bool nbls_screen_geometry(const nbls_handle* h, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl) {
+// Eligibility + LDS size of the screening path for windows of up to maxW samples.
+// *G = partners per workgroup.  All N-1 (at most 16) when their images fit; else the largest group size whose
+// images fit next to the sliding channel's eight shifted copies in a CU's 160 KB — the workgroups of a sliding
+// channel then split its partners (the mechanism that serves 18..32 elements), e.g. 8 elements x 6000 samples:
+// two groups of four; 16 elements x 4500 samples: two groups of eight.  Beyond ~7900 samples even two partners
+// do not fit (the copies alone take 16 bytes per sample): the caller falls back to the general correlator.
+bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G) {
     const int N = h->nchans;
-    if (N < 3 || N > 33 || h->maxW < 64) return false;
-    const int NPc = (N - 1) < 16 ? (N - 1) : 16;     // partners per workgroup (more than 16: partner groups)
-    *S = 16 / NPc;
-    *PFB = 16 * (*S - 1);
-    *WP = round_up(h->maxW, 16);
-    // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
-    // row of room for the per-partner skew
-    *CSB = round_up(*PFB + *WP + 192, 256) + 256;
-    // K round-up + read-ahead of the last tile of a group (sized for the eight-tile groups of the one-block instance
-    // where it may be chosen: S == 1)
-    int csa = *WP + 144 + ((*S == 1 ? 8 : TB) - 1) * 16 * (*S);
-    csa = round_up(csa, 32);
-    while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
-    *CSA = csa;
-    // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
-    // LDS, else one sliding channel (4 waves, N-1 images)
-    // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
-    // the caller when they still fit (nbls_screen_tables)
-    const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 32 * N + 64;
-    const size_t lds1 = (size_t)2 * NPc * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 32 * N + 64;
-    const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
-    if (lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
-    else { *nsl = 1; *lds = lds1; }
-    return *lds <= 160 * 1024 && *lds >= 1024;
+    if (N < 3 || N > 33 || maxW < 64) return false;
+    const int NPc = (N - 1) < 16 ? (N - 1) : 16;     // partners per workgroup when everything fits (more than 16: partner groups)
+    *WP = round_up(maxW, 16);
+    for (int g = NPc; g >= 2; --g) {
+        *G = g;
+        *S = 16 / g;
+        if (*S > 8) return false;                        // (the column decode handles up to 8 lag blocks per tile)
+        *PFB = 16 * (*S - 1);
+        // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
+        // row of room for the per-partner skew
+        *CSB = round_up(*PFB + *WP + 192, 256) + 256;
+        // K round-up + read-ahead of the last tile of a group (sized for the eight-tile groups of the one-block instance
+        // where it may be chosen: S == 1)
+        int csa = *WP + 144 + ((*S == 1 ? 8 : TB) - 1) * 16 * (*S);
+        csa = round_up(csa, 32);
+        while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
+        *CSA = csa;
+        // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
+        // LDS, else one sliding channel (4 waves, N-1 images)
+        // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
+        // the caller when they still fit (nbls_screen_tables)
+        const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 32 * N + 64;
+        const size_t lds1 = (size_t)2 * g * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 32 * N + 64;
+        const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
+        if (g == NPc && lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
+        else { *nsl = 1; *lds = lds1; }
+        if (*lds <= 160 * 1024 && *lds >= 1024) return true;
+    }
+    return false;
 }
 
-hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
+// The units [ub, ue) — consecutive bands of ONE window length W (nbls_plan: h->wgroups) — through the screening path.
+// *launches counts the unit batches (profiling events are taken from h->bev at 4 * *launches).
+hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int64_t* launches_io) {
     QArgs a{};
     size_t lds = 0;
-    if (!nbls_screen_geometry(h, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl)) return hipErrorInvalidValue;
+    if (!nbls_screen_geometry(h, gW, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl, &a.pgsz)) return hipErrorInvalidValue;
     const int N = h->nchans;
-    a.npg = (N - 1 + 15) / 16;
-    a.Wuni = h->uniW;
+    a.npg = (N - 1 + a.pgsz - 1) / a.pgsz;
+    a.Wuni = gW;
     {   // energy tables in LDS when they do not cost occupancy (two workgroups per CU, or still one)
         const size_t tab = (size_t)(a.nsl + N) * (a.WP / 32 + 2) * 4;
         const size_t cap = lds <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
@@ -1436,8 +1393,6 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     a.dyn = h->opt.screen_static ? 0 : 1;
-    a.b_dma = h->opt.screen_b_dma ? 1 : 0;
-    a.kold = h->opt.screen_kold ? 1 : 0;
     {
         const unsigned long long d = (unsigned long long)(a.WP / 32 + 2);      // exact for every index below 2^32 / d
         a.tab_inv = (unsigned int)(((1ull << 32) + d - 1) / d);
@@ -1455,7 +1410,8 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         if (h->skew_n != N || h->skew_s != a.S) {
             int o[32] = {0};
             long budget = 200000;
-            if (N > 16 || !boff_dfs(o, 0, N, a.S, &budget))
+            // (partner groups smaller than the array: the solved skew assumes all N-1 partners in one workgroup)
+            if (N > 16 || a.pgsz < N - 1 || !boff_dfs(o, 0, N, a.S, &budget))
                 for (int q = 0; q < 32; ++q) o[q] = q & 15;   // consecutive partners of a group: distinct slots
             for (int q = 0; q < 32; ++q) h->skew_o[q] = o[q];
             h->skew_n = N;
@@ -1471,51 +1427,66 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
     hipError_t e = hipFuncSetAttribute(tb8 ? (const void*)screen_kernel<8> : (const void*)screen_kernel<4>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    size_t vlds = ((size_t)N * h->maxW + 2) * sizeof(double);   // + the zero slot
-    if (h->opt.verify_global) vlds = 1u << 30;
+    size_t vlds = ((size_t)N * gW + 2) * sizeof(double);   // + the zero slot
     if (vlds <= 80 * 1024) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
         if (e != hipSuccess) return e;
     }
     // persistent double-buffered verifier (verify_dma_kernel): up to 8 elements, the unit's windows twice in LDS
-    const int vwp = (h->maxW + 3) & ~1;                                  // LDS row stride: even, >= W + 2
+    const int vwp = (gW + 3) & ~1;                                       // LDS row stride: even, >= W + 2
     const size_t dlds = ((size_t)2 * N * vwp + 2) * sizeof(double) + (size_t)2 * h->nbands * sizeof(int);
-    const bool vdma = !h->opt.verify_global && !h->opt.verify_block && N <= 8 && h->npairs <= 32 && dlds <= 160 * 1024 &&
+    const bool vdma = N <= 8 && h->npairs <= 32 && dlds <= 160 * 1024 &&
                       (h->npts_pad & 1) == 0;
     if (vdma) {
         e = hipFuncSetAttribute((const void*)verify_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);
         if (e != hipSuccess) return e;
     }
-    int64_t launches = 0;
-    const int64_t nbatch = (h->nunits + h->screen_batch - 1) / h->screen_batch;
+    int64_t launches = *launches_io;
+    // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache; equal batches (a
+    // multiple of 8 units, the XCD grouping of the screening grid) instead of full ones plus a remainder: a 200-unit
+    // tail batch pays four kernel launches and their drain for next to nothing
+    int64_t batch = h->screen_batch;
+    {
+        const int64_t U = ue - ub;
+        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 96;
+        int64_t bw = (int64_t)(batch_mb << 20) / ((int64_t)N * 2 * a.WP);
+        if (bw < 64) bw = 64;
+        if (bw < batch) batch = bw;                  // (never more than the buffers were sized for)
+        if (batch > U) batch = U > 0 ? U : 1;
+        if (U > batch) {
+            const int64_t nb_ = (U + batch - 1) / batch;
+            const int64_t eq = ((U + nb_ - 1) / nb_ + 7) / 8 * 8;
+            if (eq < batch) batch = eq;
+        }
+    }
+    const int64_t nbatch = (ue - ub + batch - 1) / batch;
     if (h->prof) {
-        while ((int64_t)h->bev.size() < 4 * nbatch) {
+        while ((int64_t)h->bev.size() < 4 * (launches + nbatch)) {
             hipEvent_t ev;
             if (hipEventCreate(&ev) != hipSuccess) return hipErrorOutOfMemory;
             h->bev.push_back(ev);
         }
     }
-    h->bev_used = 0;
-    for (int64_t u0 = 0; u0 < h->nunits; u0 += h->screen_batch) {
+    for (int64_t u0 = ub; u0 < ue; u0 += batch) {
         a.u0 = (int)u0;
-        a.nu = (int)((h->nunits - u0) < h->screen_batch ? (h->nunits - u0) : h->screen_batch);
+        a.nu = (int)((ue - u0) < batch ? (ue - u0) : batch);
+        h->last_batch = a.nu;
         hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
         {
             const int gpl = (a.WP / 8 + 63) / 64;          // 8-sample groups per lane
             const size_t qlds = (size_t)4 * (a.WP / 8 + 8) * sizeof(double);
-            const bool slab = h->opt.quantize_slab != 0;                        // option: the LDS-slab form
             // (one instance per group count: a lane holds 8 G samples in registers, and the registers set how many
             //  waves hide the HBM latency of this streaming kernel)
-            if (gpl <= 2 && !slab)
+            if (gpl <= 2)
                 hipLaunchKernelGGL((quantize_reg_kernel<2>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
-            else if (gpl == 3 && !slab)
+            else if (gpl == 3)
                 hipLaunchKernelGGL((quantize_reg_kernel<3>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
-            else if (gpl <= 4 && !slab)
+            else if (gpl <= 4)
                 hipLaunchKernelGGL((quantize_reg_kernel<4>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
-            else if (gpl <= 6 && !slab)
+            else if (gpl <= 6)
                 hipLaunchKernelGGL((quantize_reg_kernel<6>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
-            else if (gpl <= 8 && !slab)
+            else if (gpl <= 8)
                 hipLaunchKernelGGL((quantize_reg_kernel<8>), dim3(xcd_grid(4, a.nu * N)), dim3(256), qlds, h->stream, a);
             else {
                 // one LDS slab per wave: as many waves per workgroup (<= 4) as fit a CU's 160 KB
@@ -1560,10 +1531,22 @@ hipError_t nbls_launch_xcorr_screen(nbls_handle* h) {
         }
         ++launches;
     }
+    *launches_io = launches;
+    return hipGetLastError();
+}
+
+// After the last window group of a pass (nbls_launch_xcorr): the hand-over to a chained pass and the join with the
+// solve stream.
+hipError_t nbls_xcorr_screen_finish(nbls_handle* h, int64_t launches) {
     // the correlation stage of this pass is queued: a pass chained behind it (nbls_execute_after) may start its own
     // correlation stage here — BEFORE the join below, so that it runs beside this pass's last solve
     if (h->ev_xd) { (void)hipEventRecord(h->ev_xd, h->stream); h->ev_xd_recorded = true; h->ev_xd_by_launcher = true; }
     if (h->fuse_solve) {       // join: everything later on `stream` sees the solves
+        while ((int64_t)h->pev.size() <= launches) {
+            hipEvent_t pe;
+            if (hipEventCreateWithFlags(&pe, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+            h->pev.push_back(pe);
+        }
         (void)hipEventRecord(h->pev[launches], h->stream2);
         (void)hipStreamWaitEvent(h->stream, h->pev[launches], 0);
         h->solve_done = true;

@@ -196,9 +196,10 @@ def test_raw_trace_with_a_gap_propagates_like_sosfilt(oracle):
 
 
 def test_long_windows_of_example_py_at_100_hz(oracle):
-    """example.py's adaptive WINLEN_1 = 60 s on 100 Hz data (cfg-4's rate) is W = 6000 samples — beyond round 1's
-    3840-sample cap.  With 8 elements the int8 images no longer fit LDS, the general FP64 correlator (two windows
-    in 96 KB of LDS) takes over: lags, maxima and the solution exactly the oracle's."""
+    """example.py's adaptive WINLEN_1 = 60 s on 100 Hz data (cfg-4's rate) is W = 6000 samples.  With 8 elements the
+    int8 images of all seven partners no longer fit a CU's LDS next to the sliding channel's copies: the screening
+    kernel now splits the partners into two groups of four (the mechanism that serves 18..32 elements) instead of
+    handing the plan to the general FP64 correlator — lags, maxima and the solution exactly the oracle's."""
     fs, nchans, winlen = 100.0, 8, 60.0
     rij = synthetic.array_geometry(nchans, 1.0, seed=77)
     data = synthetic.plane_wave(rij, int(2.6 * winlen * fs), fs, 0.2, 4.0, seed=9)
@@ -208,12 +209,76 @@ def test_long_windows_of_example_py_at_100_hz(oracle):
     h.set_profiling(True)
     try:
         _compare_ltsva(oracle, c, st, winlen, 1.0)
-        assert h.timings()['xcorr_impl'] == 1            # the VALU correlator with > 64 KB of dynamic LDS
+        tm = h.timings()
+        assert tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 0
     finally:
         h.set_profiling(False)
     with pytest.raises(ValueError, match='10000'):
         from narrow_band_least_squares_amd import ltsva
         ltsva(synthetic.make_stream(data, fs), None, None, 120.0, 0.5, 1.0, rij=c['rij'])     # W = 12000: the documented limit
+
+
+@pytest.mark.parametrize('nchans,W,noise', [(8, 6000, False), (8, 6000, True), (16, 3200, True), (16, 4500, False), (16, 4500, True),
+                                            (12, 5003, True), (5, 7400, True), (24, 3100, True)])
+def test_partner_groups_extend_the_screening_correlator_to_long_windows(nchans, W, noise):
+    """Window lengths whose int8 images do not fit a CU's LDS with all partners in one workgroup: partner groups of
+    8 / 4 / 2 (tile geometry: 2 / 4 / 8 lag blocks per tile column, linear skew).  Lags must be those of the plain
+    VALU correlator, on a plane wave and on incoherent noise (arg-max anywhere among the 2W-1 lags: every lag block
+    of every column is exercised), for window lengths that are not multiples of the tile steps too."""
+    fs = 100.0
+    rng = np.random.default_rng(W + nchans)
+    rij = synthetic.array_geometry(nchans, 1.0, seed=nchans)
+    npts = int(2.3 * W)
+    data = rng.standard_normal((nchans, npts)) if noise else synthetic.plane_wave(rij, npts, fs, 0.5, 20.0, seed=3)
+    kw = dict(want_lag=True, want_cmax=True)
+    edges = [(0.5, 20.0)]
+    wl = [W / fs + 1e-9]
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        got = engine.process(data, fs, 0.0, rij, edges, wl, 0.5, 1.0, 'butter', 2, 0.01, **kw)
+        tm = h.timings()
+        assert tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 0
+    finally:
+        h.set_profiling(False)
+    assert int(got.W[0]) == W
+    ref = engine.process(data, fs, 0.0, rij, edges, wl, 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=1, **kw)
+    if noise:
+        assert np.abs(ref.lag).max() > W // 3
+    np.testing.assert_array_equal(got.lag, ref.lag)
+    np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(got.baz, ref.baz)
+
+
+def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
+    """example.py's adaptive windows 60 -> 30 s at 100 Hz in ONE call, plus a 90 s band (W = 9000: beyond what the
+    screening kernel can hold even with two partners per group): every band of a screenable window length is screened,
+    only the 90 s band runs on the general correlator — no longer the whole plan.  Rows against the oracle."""
+    from narrow_band_least_squares_amd import helpers
+    fs, nchans = 100.0, 8
+    rij = synthetic.array_geometry(nchans, 1.0, seed=5)
+    data = synthetic.plane_wave(rij, 40000, fs, 0.1, 5.0, seed=21)
+    winlens = [90.0] + helpers.get_winlenlist('adaptive', 4, 50, 60, 30)
+    edges = [(0.1, 0.3), (0.3, 0.6), (0.6, 1.2), (1.2, 2.4), (2.4, 4.8)]
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        got = engine.process(data, fs, 17884.0729166667, rij - rij.mean(axis=1, keepdims=True), edges, winlens, 0.5, 1.0, 'butter', 2, 0.01,
+                             want_lag=True)
+        tm = h.timings()
+        assert tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 1
+    finally:
+        h.set_profiling(False)
+    st = oracle.make_stream(data, fs, starttime=17884.0729166667)
+    for b, (lo, hi) in enumerate(edges):
+        stf, _, _ = oracle.filter_data(st, 'butter', lo, hi, 2, 0.01)
+        out, internals = oracle.ltsva(stf, None, None, winlens[b], 0.5, 1.0, rij=rij - rij.mean(axis=1, keepdims=True), return_internals=True)
+        n = int(got.nwin[b])
+        assert n == len(out[0]) and n >= 1
+        np.testing.assert_array_equal(got.lag[b, :n], np.rint(internals['tau'].T * fs).astype(int))
+        np.testing.assert_allclose(got.vel[b, :n], out[0], rtol=1e-9)
+        np.testing.assert_allclose(got.baz[b, :n], out[1], rtol=1e-9)
+        np.testing.assert_allclose(got.mdccm[b, :n], out[3], rtol=1e-9)
 
 
 @pytest.mark.parametrize('ftype,alpha', [('butter', 1.0), ('cheby1', 0.5)])

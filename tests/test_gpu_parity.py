@@ -302,12 +302,12 @@ def test_kernel_variants_agree(monkeypatch):
     try:
         r_gen = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
         # the other identical-result switches of the library, all at once
-        for key in ('verify_global', 'verify_block', 'screen_b_dma', 'screen_kold', 'screen_tb4', 'quantize_slab', 'screen_nsl1', 'filter_nofuse', 'filter_nomfma', 'filter_store_y1', 'lts_generic_h'):
+        for key in ('screen_tb4', 'screen_nsl1', 'screen_static', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
             h.set_option(key, 1)
         h.set_option('lts_impl', 0)
         r_alt = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=3, **kw)
     finally:
-        for key in ('lts_impl', 'verify_global', 'verify_block', 'screen_b_dma', 'screen_kold', 'screen_tb4', 'quantize_slab', 'screen_nsl1', 'filter_nofuse', 'filter_nomfma', 'filter_store_y1', 'lts_generic_h'):
+        for key in ('lts_impl', 'screen_tb4', 'screen_nsl1', 'screen_static', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
             h.set_option(key, 0)
     np.testing.assert_array_equal(r_alt.lag, r_mfma.lag)
     for k in ('vel', 'baz', 'weights'):
