@@ -273,13 +273,20 @@ def main():
         h.set_profiling(False)
         return kern, stages
 
+    step_times = []        # wall time of every timed call of the LAST timed() run (the calls are synchronous)
+
     def timed(stream, steps, resident=False):
         barrier()
         t0 = time.perf_counter()
         out = None
         held = []          # the results of the timed calls stay alive until the clock has stopped: tearing down the
+        del step_times[:]
+        tp = t0
         for _ in range(steps):   # PREVIOUS call's 5*10^4-entry dictionary (1-2 ms) is the caller's business, not the call's
             out = one_call(stream, resident)
+            tn = time.perf_counter()
+            step_times.append((tn - tp) * 1e3)
+            tp = tn
             if len(held) < 128:
                 held.append(out)
         barrier()
@@ -312,6 +319,31 @@ def main():
         print(failure, file=sys.stderr)
         give_up(failure + '; not measured (no fallback to --shard traces: that is a different, weak-scaling measurement)')
     elapsed, out = timed(st, args.steps)
+    steps_ms = sorted(step_times)
+
+    def in_call_stage_ms(stream, reps=3):
+        """Stage times INSIDE whole calls: the profiling events of every handle the call used (its band groups run on
+        up to four handles of the GPU, their kernels overlap at the seams and stretch), summed over the groups —
+        beside `kernel_only_ms`, which is one pass of all bands executed back to back."""
+        hs = [hd for (pid, dev, slot), hd in sorted(engine._handles.items()) if pid == os.getpid()]
+        for hd in hs:
+            hd.set_profiling(True)
+        acc = []
+        try:
+            for _ in range(reps):
+                one_call(stream)
+                tot = {}
+                for hd in hs:
+                    with contextlib.suppress(Exception):
+                        tm = hd.timings()
+                        for k in ('filter_ms', 'quantize_ms', 'screen_ms', 'verify_ms', 'solve_ms', 'xcorr_ms'):
+                            tot[k] = tot.get(k, 0.0) + float(tm[k])
+                acc.append(tot)
+        finally:
+            for hd in hs:
+                hd.set_profiling(False)
+        return {k: float(np.median([a_.get(k, 0.0) for a_ in acc])) for k in acc[0]} if acc else {}
+    in_call = in_call_stage_ms(st) if (not multi and call_args is not None) else {}
     kern, stages = measure_kernels(st, max(3, args.steps // 2))
     nwin_list = out[6]
     units_call = int(sum(nwin_list))
@@ -352,6 +384,8 @@ def main():
         line = {
             'metric': '(window x band) LTS solves/sec, 8-element synthetic', 'value': value, 'unit': 'solves/s',
             'n_gpus': ngpu, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'ms_per_step_min_median_max': [steps_ms[0], float(np.median(steps_ms)), steps_ms[-1]],
+            'value_median_step': total_units / (float(np.median(steps_ms)) * 1e-3),
             'higher_is_better': True, 'scaling': 'weak' if (shard_traces or not multi) else 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': LABELS.get(args.config, args.config) + ', %s s windows %d%% overlap, %s order %d%s'
@@ -370,13 +404,17 @@ def main():
                        'scale': args.scale},
             'kernel_only_ms': kernel_only,
             'kernel_only_value': units_gpu / (kernel_only * 1e-3) * (ngpu if multi else 1),
+            'stage_ms_in_call': {k.replace('_ms', ''): v for k, v in in_call.items()} or None,
             'stage_ms': {'filter': mean('filter_ms'), 'xcorr': mean('xcorr_ms'), 'solve': mean('solve_ms'),
                          'xcorr_quantize': mean('quantize_ms'), 'xcorr_screen': mean('screen_ms'),
                          'xcorr_verify': mean('verify_ms')},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved_tf / peak, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
                          'kernel_ms_per_step': kern_ms, 'launches_per_step': launches,
-                         'note': 'ALGORITHMIC fraction: 2*P*W^2 flop per unit x units / kernel time, not issued work '
+                         'kernel_ms_in_call': in_call.get('screen_ms') if impl_used == 3 else in_call.get('xcorr_ms'),
+                         'frac_in_call': (flop_total / (in_call['screen_ms'] * 1e-3) / 1e12 / peak) if (impl_used == 3 and in_call.get('screen_ms')) else None,
+                         'note': 'frac: one pass of all bands executed back to back; frac_in_call: the same kernel inside whole calls '
+                                 '(sum over the call\'s band groups, HIP events per handle). ALGORITHMIC fraction: 2*P*W^2 flop per unit x units / kernel time, not issued work '
                                  '(the screening kernel issues 3 int8 limb products per multiply-add and skips lag '
                                  'blocks that cannot hold the maximum; see `noise` for the input without coherent signal)'},
             'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_total / (ms_step * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
