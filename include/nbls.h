@@ -276,7 +276,7 @@ int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32
 
 /* Developer statistic of the int8 screening correlator (last unit batch): out4 = {ordered pairs,
  * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
-int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4);
+int nbls_debug_screen_stats(nbls_handle* h, int64_t* out8);
 /* Developer: mean s_memtime cycle counts of the phases of the wave-per-unit FAST-LTS kernel
 (developer build, options "screen_stamps" / "lts_stamps"): out8 = {setup+medians, elemental starts,
  * C-steps, candidate peel, refinement, finish, 0, total}. */

@@ -387,9 +387,10 @@ class Handle:
         return dict(zip(('groups', 'merge', 'compact', 'live_entries_total', 'w0_passes', 'w0_select', 'w0_sums', 'w0_groups'), out))
 
     def screen_stats(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 8)()
         self._chk(self.lib.nbls_debug_screen_stats(self._h, out))
-        return dict(pairs=out[0], overflow=out[1], candidates=out[2], max_candidates=out[3])
+        return dict(pairs=out[0], overflow=out[1], candidates=out[2], max_candidates=out[3], lag_runs=out[4],
+                    lags_in_runs_of_2_or_more=out[5])
 
     def probe_mfma_i8(self, a, b):
         """a, b: (64, 16) int8 per-lane fragments -> (64, 4) int32 accumulators."""

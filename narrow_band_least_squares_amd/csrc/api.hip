@@ -1,5 +1,6 @@
 // C ABI of libnbls_hip.so (see include/nbls.h): handle, HBM buffers, plan, launch order.
 #include "nbls_internal.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -921,7 +922,7 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
     const int64_t last = h->last_batch > 0 ? h->last_batch : h->nunits - ((h->nunits - 1) / h->screen_batch) * h->screen_batch;
     std::vector<int32_t> c((size_t)last * N * N * 32);
     HIPCHK(h, copy_sync(h, c.data(), h->d_cand, c.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (int q = 0; q < 8; ++q) out4[q] = 0;
     for (int64_t u = 0; u < last; ++u)
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) {
@@ -931,6 +932,18 @@ int nbls_debug_screen_stats(nbls_handle* h, int64_t* out4) {
                 out4[1] += e[1] != 0;          // interval and/or list overflow
                 out4[2] += e[0];
                 if (e[0] > out4[3]) out4[3] = e[0];
+                // how the listed lags cluster (developer: what a verifier that shares loads between adjacent lags could use)
+                int n = e[0] < 26 ? e[0] : 26;
+                int v[26];
+                for (int q = 0; q < n; ++q) v[q] = e[6 + q];
+                std::sort(v, v + n);
+                for (int q = 0; q < n; ) {
+                    int r = q + 1;
+                    while (r < n && v[r] == v[r - 1] + 1) ++r;
+                    out4[4] += 1;                       // runs of consecutive lags
+                    if (r - q >= 2) out4[5] += r - q;   // listed lags that sit in a run of two or more
+                    q = r;
+                }
             }
     return NBLS_OK;
 }
