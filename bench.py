@@ -200,7 +200,22 @@ def main():
         call_args = None
     edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in bands]
 
-    h = engine.get_handle()          # NBLS_DEVICE, else LOCAL_RANK (one process per GPU), else 0
+    # NBLS_DEVICE, else LOCAL_RANK (one process per GPU), else 0.  A rank without a GPU (fewer devices than ranks) must not
+    # leave the others waiting in a collective: every rank learns of it and the run ends with the "failed" line.
+    h, herr = None, None
+    try:
+        h = engine.get_handle()
+    except Exception as e:      # noqa: BLE001
+        herr = 'rank %d cannot open its GPU (%s: %s)' % (rank, type(e).__name__, e)
+    if td is not None:
+        import torch
+        flag = torch.tensor([1 if herr else 0])
+        td.all_reduce(flag, op=td.ReduceOp.MAX)
+        if int(flag.item()) and herr is None:
+            herr = 'another rank cannot open its GPU (fewer GPUs than ranks?)'
+    if herr:
+        print(herr, file=sys.stderr)
+        give_up(herr + '; not measured')
 
     def one_call(stream, resident=False):
         planner.design_cache_clear()
