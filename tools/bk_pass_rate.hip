@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void k(const double* __restrict__ xs, const do
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int rep = 0; rep < reps; ++rep) {
         if (MODE == 0) {
-            BK_HIST_PASS(P, xs, y, nbls_bucket::bin_of_hw_clamp(lo_hw, sh, hw));
+            BK_HIST_PASS(P, xs, y, nbls_bucket::bin_of_hw(lo_hw, sh, hw));
         } else if (MODE == 5) {
             FakeL L{y};
             double obj = 0, sxx = 0, sxy = 0, syy = 0, bx = 0, by = 0;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void k(const double* __restrict__ xs, const do
                 const double c0 = (MODE == 3 || MODE == 4) ? ca : xs[2 * kk];
                 const double c1 = (MODE == 3 || MODE == 4) ? cb : xs[2 * kk + 1];
                 const double r = (yk - c0 * z0) - c1 * z1;
-                const int b = nbls_bucket::bin_of_hw_clamp(lo_hw, sh, bk_key_hw(r));
+                const int b = nbls_bucket::bin_of_hw(lo_hw, sh, bk_key_hw(r));
                 if (MODE == 1 || MODE == 4) asum += (unsigned int)b;
                 else __hip_atomic_fetch_add(col + b * RS, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ya += 1e-9; ca += 1e-9;

@@ -1,8 +1,8 @@
-# Evidence for profiles/: run through gpurun from the repo root:  gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
+# Evidence for profiles/: run through gpurun from the repo root:  gpurun --timeout 1100 -- 'bash tools/profile_round.sh r03'
 #   1./2. FETCH_SIZE / WRITE_SIZE PMC passes of the bench command (cfg-3) -> traffic.json (per kernel, per pass)
 #   3.    bench JSON line of every configuration (cfg-3 reads that traffic.json)
 #   4.    rocprofv3 --kernel-trace --stats of the same bench command per configuration
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -19,4 +19,15 @@ done
 bash tools/pmc_traffic.sh cfg3 1 > $OUT/${TAG}_pmc_traffic_per_pass.txt 2>&1
 bash tools/pmc_screen.sh 1 > $OUT/${TAG}_sq_counters.txt 2>&1
 python tools/call_breakdown.py 2>&1 | grep -v CAUTION > $OUT/${TAG}_call_breakdown.txt
+# the large-array FAST-LTS kernel (solve_bucket.inc): SQ counters + instructions per wave, developer phase stamps
+bash tools/pmc_lts.sh cfg5 1 > $OUT/${TAG}_lts_sq_counters_cfg5.txt 2>&1
+bash tools/pmc_lts.sh cfg4 0.25 bands=12 > $OUT/${TAG}_lts_sq_counters_cfg4.txt 2>&1
+if [ -f narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so ]; then
+  for C in "cfg5 1" "cfg4 0.25 bands=12"; do
+    NBLS_LIB=narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so python tools/quick_time.py $C 2 lts_stamps=1 2>&1 | grep -v CAUTION | tail -n 4
+  done > $OUT/${TAG}_lts_stamps.txt
+fi
+python tools/long_window_time.py 2>&1 | grep -v CAUTION > $OUT/${TAG}_long_window_time.txt
+[ -x tools/lds_atomic_rate ] && ./tools/lds_atomic_rate > $OUT/${TAG}_lds_atomic_rate.txt 2>&1
+[ -x tools/bk_pass_rate ] && ./tools/bk_pass_rate > $OUT/${TAG}_bk_pass_rate.txt 2>&1
 ls $OUT
