@@ -46,16 +46,20 @@ def get_handle(device=None, slot=0):
     return h
 
 
-def pipeline_groups(nwin):
+def pipeline_groups(nwin, npairs=28):
     """Into how many band groups a call is cut (``NBLS_PIPELINE_GROUPS`` overrides).  Each group is its own
     asynchronous pass on its own handle of the same GPU: while the GPU works on group k, the host designs the
     filters of group k+1, and later turns the finished groups' weights into the dropped-element dictionary
-    while the remaining groups are still being computed.  Small calls are one group."""
+    while the remaining groups are still being computed.  Small calls are one group.  "Small" is measured in units
+    weighted by the pair count (a unit of a 32-element array costs ~20x the GPU time of an 8-element one, and its
+    dictionary entry — up to 62 mask bytes, a value array of its own — several times the host time: at 32 elements x
+    128 bands the dictionary of a single-group call was a 15-25 ms tail behind the GPU)."""
     env = os.environ.get('NBLS_PIPELINE_GROUPS')
     nb = len(nwin)
     if env:
         return max(1, min(nb, int(env)))
-    return max(1, min(4, nb, int(np.sum(nwin)) // 16000))
+    weight = max(1.0, float(npairs) / 28.0)
+    return max(1, min(4, nb, int(np.sum(nwin) * weight) // 16000))
 
 
 def stream_to_array(st):
@@ -396,7 +400,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                                  filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
                                  group_done)
     cap = max(1, cap)
-    ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin))
+    ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
     ngroups = max(1, min(ngroups, nb))
     # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
     # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
