@@ -968,13 +968,52 @@ __device__ inline void wave_dot(const double* xa, const double* xb, const double
     for (int q = 0; q < NQ; ++q) out[q] = wave_sum_f64(acc[q]);
 }
 
+// R CONSECUTIVE candidate lags k0 .. k0+R-1 of one pair at once (long windows of low-frequency bands: the lags within
+// the screening bound of the maximum form one run of ~4 around the peak — cfg-4: 3.7 candidates per ordered pair, 97 %
+// of them in runs).  The R shifted reads of xa are one coalesced load per 64 samples plus R conflict-free LDS reads of
+// a 64 + R - 1 sample chunk (scr: per-wave scratch), instead of R loads: the global-memory verifier is bound by the
+// vector-memory path (5 loads per 4 multiply-adds), this form needs 2.
+constexpr int VRUN_U = 8;                       // 64-sample steps per trip of wave_dot_run (their loads are in flight together)
+constexpr int VRUN_SCR = 64 * VRUN_U + 8;       // doubles of per-wave scratch
+template <int R>
+__device__ inline void wave_dot_run(const double* xa, const double* xb, int W, int k0, int lane, double* scr, double (&out)[4]) {
+    const int d0 = k0 - (W - 1);
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = 0.0;
+    for (int nb = 0; nb < W; nb += 64 * VRUN_U) {
+        double vb[VRUN_U], va[VRUN_U];
+#pragma unroll
+        for (int u = 0; u < VRUN_U; ++u) {
+            const int n = nb + 64 * u + lane;
+            const int m = n + d0;
+            vb[u] = n < W ? xb[n] : 0.0;
+            va[u] = ((unsigned)m < (unsigned)W) ? xa[m] : 0.0;
+        }
+        double vx = 0.0;                                 // the R - 1 samples behind the last step's chunk
+        if (lane < R - 1) { const int mx = nb + 64 * VRUN_U + lane + d0; vx = ((unsigned)mx < (unsigned)W) ? xa[mx] : 0.0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the previous trip's chunk has been read
+#pragma unroll
+        for (int u = 0; u < VRUN_U; ++u) scr[64 * u + lane] = va[u];
+        if (lane < R - 1) scr[64 * VRUN_U + lane] = vx;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // (LDS is in order per wave; this also covers a generic-pointer store)
+#pragma unroll
+        for (int u = 0; u < VRUN_U; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(scr[64 * u + lane + q], vb[u], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) out[q] = wave_sum_f64(acc[q]);
+}
+
 // Verify one pair: xa/xb point at the two channel windows (LDS or global).  The two 32-int candidate
 // records are fetched with ONE load per lane (lanes 0-31: i->j record, 32-63: j->i) and read back with
 // wave-uniform shuffles, so the wave does not chase a chain of dependent global loads.
 // A direction whose screening maximum lies more than theta below the other direction's cannot hold
 // the arg-max (same test as inside the screening kernel) and is dropped without any FP64 work.
 __device__ inline void verify_pair(const double* xa, const double* xb, const double* zero, int W, int rec,
-                                   double ssa, double ssb, int lane, double* best_out, int* bestk_out) {
+                                   double ssa, double ssb, int lane, double* best_out, int* bestk_out, double* scr = nullptr) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
     if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {
@@ -1005,6 +1044,40 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
         const int nr0 = r0hi >= r0lo ? r0hi - r0lo + 1 : 0;
         const int nr1 = r1hi >= r1lo ? r1hi - r1lo + 1 : 0;
         const int total = nlist + nr0 + nr1;
+        if (scr != nullptr && total >= 2) {
+            // ---- run form: the listed lags sorted (rank count across the lanes that hold them), then runs of up to
+            //      four consecutive lags share their loads; intervals are runs by construction ----
+            // (every lane takes part in the shuffle: a permute reads nothing from lanes that are switched off)
+            const int src = lane < n1 ? CHDR + lane : 32 + CHDR + lane - n1;
+            const int got = __shfl(rec, src & 63, 64);
+            const int cv = lane < nlist ? got : 0x7fffffff;
+            int rank = 0;
+            for (int u = 0; u < nlist; ++u) {
+                const int cu = __builtin_amdgcn_readlane(cv, u);
+                rank += (cu < cv) || (cu == cv && u < lane);
+            }
+            const int srt = __builtin_amdgcn_ds_permute((lane < nlist ? rank : lane) * 4, cv);     // srt[rank] = cv
+            auto run_from = [&](int k0, int len) {           // lags k0 .. k0+len-1, len <= 4, wave-uniform
+                double v[4] = {0.0, 0.0, 0.0, 0.0};
+                if (len >= 4) wave_dot_run<4>(xa, xb, W, k0, lane, scr, v);
+                else if (len == 3) wave_dot_run<3>(xa, xb, W, k0, lane, scr, v);
+                else if (len == 2) wave_dot_run<2>(xa, xb, W, k0, lane, scr, v);
+                else { const int kk1[4] = {k0, -1, -1, -1}; wave_dot<1>(xa, xb, zero, W, kk1, lane, v); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < len && better(v[q], k0 + q, best, bestk)) { best = v[q]; bestk = k0 + q; }
+            };
+            for (int p = 0; p < nlist; ) {
+                const int k0 = __builtin_amdgcn_readlane(srt, p);
+                int len = 1;
+                while (len < 4 && p + len < nlist && __builtin_amdgcn_readlane(srt, p + len) == k0 + len) ++len;
+                run_from(k0, len);
+                p += len;
+                while (p < nlist && __builtin_amdgcn_readlane(srt, p) < k0 + len) ++p;      // (a lag listed by both directions)
+            }
+            for (int lo = r0lo; lo <= r0hi; lo += 4) run_from(lo, r0hi - lo + 1 < 4 ? r0hi - lo + 1 : 4);
+            for (int lo = r1lo; lo <= r1hi; lo += 4) run_from(lo, r1hi - lo + 1 < 4 ? r1hi - lo + 1 : 4);
+        } else
         for (int q0 = 0; q0 < total; q0 += 4) {
             int kk[4];
             double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1234,6 +1307,7 @@ __global__ __launch_bounds__(1024) void verify_dma_kernel(QArgs a, int wp, int n
 }
 
 __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
+    __shared__ double vscr[4][VRUN_SCR];            // per wave: a chunk of the sliding window (wave_dot_run)
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int P = a.npairs, N = a.nchans;
@@ -1253,7 +1327,7 @@ __global__ __launch_bounds__(256) void verify_kernel(QArgs a) {
     const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
     const int rec = lane < 32 ? l1[lane] : l2[lane - 32];
     verify_pair(a.filt + ((int64_t)band * N + ci) * a.npts_pad + t0, a.filt + ((int64_t)band * N + cj) * a.npts_pad + t0,
-                a.qmeta + 3 /* always 0.0 */, W, rec, ssa, ssb, lane, &best, &bestk);
+                a.qmeta + 3 /* always 0.0 */, W, rec, ssa, ssb, lane, &best, &bestk, vscr[threadIdx.x >> 6]);
     if (lane == 0) {
         const int64_t o = ((int64_t)band * a.vector_len + w) * P + k;
         a.lag[o] = (W - 1) - bestk;
