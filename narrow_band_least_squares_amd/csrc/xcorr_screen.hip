@@ -1502,7 +1502,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t vlds = ((size_t)N * gW + 2) * sizeof(double);   // + the zero slot
-    if (vlds <= 80 * 1024) {
+    if (vlds <= 158 * 1024) {
         e = hipFuncSetAttribute((const void*)verify_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
         if (e != hipSuccess) return e;
     }
@@ -1585,7 +1585,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
             const int share = (a.nu + 7) >> 3;
             const int per_xcd = h->num_cus > 0 ? (h->num_cus + 7) / 8 : 32;      // one workgroup per CU
             hipLaunchKernelGGL(verify_dma_kernel, dim3(8 * (share < per_xcd ? share : per_xcd)), dim3(1024), dlds, h->stream, a, vwp, h->nbands);
-        } else if (vlds <= 80 * 1024)
+        } else if (vlds <= 158 * 1024)
             hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(512), vlds, h->stream, a);
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
