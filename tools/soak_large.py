@@ -1,5 +1,6 @@
 """Developer: one-off soak of ltsva() with 9..24 elements (the cooperative FAST-LTS kernel, partner-group screening)
-against the oracle: lags, weights, z exactly / to 1e-9.    python tools/soak_large.py FIRST LAST"""
+against the oracle: lags, weights, z exactly / to 1e-9.    python tools/soak_large.py FIRST LAST [NLO NHI]
+(NLO NHI = 24 33: the u16-counter / no-merging form of the large-array LTS kernel, more than 255 pairs)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]
@@ -9,10 +10,11 @@ import nbls_oracle as oracle
 import test_gpu_parity as T
 from narrow_band_least_squares_amd import synthetic
 first, last = int(sys.argv[1]), int(sys.argv[2])
+nlo, nhi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (9, 25)      # element counts [nlo, nhi)
 bad = 0
 for seed in range(first, last):
     rng = np.random.default_rng(5000 + seed)
-    nchans = int(rng.integers(9, 25))
+    nchans = int(rng.integers(nlo, nhi))
     fs = float(rng.choice([20.0, 40.0]))
     winlen = float(rng.choice([15.0, 20.0, 30.0]))
     npts = int((rng.uniform(5.0, 9.0) * winlen) * fs)
