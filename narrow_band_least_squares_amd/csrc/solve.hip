@@ -622,11 +622,24 @@ __device__ inline void subset_le(const double (&a)[PT], double T, unsigned int& 
     auto one = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const unsigned int in = (a[k] <= T) ? 1u : 0u;
-        cnt += (int)in;
         obj = __builtin_fma(a[k] * a[k], (double)in, obj);
         mask |= in << k;
     };
     (one(std::integral_constant<int, K>{}), ...);
+    cnt += __popc(mask);
+}
+
+// Ties across position h (cnt > h for the h-th smallest value T): the stable-rank subset is every a_k < T plus the
+// FIRST h - #{a_k < T} of the a_k == T in index order.  On real lags this is not rare — closure (lag_ik = lag_ij +
+// lag_jk, x_ik = x_ij + x_jk) makes r_ik = r_jk wherever a start's own pair has r_ij = 0 — so it must not cost the
+// O(P^2) rank count: one equality mask, a few bit operations, and the objective again over the final subset.
+template <int PT, int... K>
+__device__ inline void eq_mask(const double (&a)[PT], double T, unsigned int& meq, std::integer_sequence<int, K...>) {
+    ((meq |= (a[K] == T ? 1u : 0u) << K), ...);
+}
+template <int PT, int... K>
+__device__ inline void obj_of_mask(const double (&a)[PT], unsigned int mask, double& obj, std::integer_sequence<int, K...>) {
+    ((obj = __builtin_fma(a[K] * a[K], (double)((mask >> K) & 1u), obj)), ...);
 }
 
 template <int PT, int H = 0>     // H: the plan's h when it is known at compile time (0 = run-time h)
@@ -662,6 +675,21 @@ __device__ __forceinline__ RegSel<PT> select_reg(const double* y, const double* 
             s.ok = true;
             s.mask = (unsigned long long)m;
             s.obj = obj;
+            return s;
+        }
+        if (cnt > h) {
+            unsigned int meq = 0u;
+            eq_mask<PT>(a, T, meq, Seq{});
+            const unsigned int mlt = m & ~meq;
+            const int need = h - __popc(mlt);            // 1 <= need < popc(meq)
+            unsigned int rest = meq;
+            for (int i = 0; i < need; ++i) rest &= rest - 1u;     // drop the lowest `need` tied indices
+            const unsigned int mfin = mlt | (meq & ~rest);
+            double o2 = 0.0;
+            obj_of_mask<PT>(a, mfin, o2, Seq{});
+            s.ok = true;
+            s.mask = (unsigned long long)mfin;
+            s.obj = o2;
             return s;
         }
     }

@@ -107,6 +107,22 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, double* sink, 
                          : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7])
                          : "v"(ub) : "vcc");
         }
+        if (MODE == 19) {      // integer -> double conversions (the 0/1 weights of the LTS sums)
+            asm volatile("v_cvt_f64_u32 %0, %8\nv_cvt_f64_u32 %1, %9\nv_cvt_f64_u32 %2, %10\nv_cvt_f64_u32 %3, %11\n"
+                         "v_cvt_f64_u32 %4, %12\nv_cvt_f64_u32 %5, %13\nv_cvt_f64_u32 %6, %14\nv_cvt_f64_u32 %7, %15\n"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                         : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]));
+        }
+        if (MODE == 20) {      // v_rcp_f64 / v_sqrt_f64 (the quarter-rate unit) for comparison
+            asm volatile("v_rcp_f64 %0, %0\nv_rcp_f64 %1, %1\nv_rcp_f64 %2, %2\nv_rcp_f64 %3, %3\n"
+                         "v_rcp_f64 %4, %4\nv_rcp_f64 %5, %5\nv_rcp_f64 %6, %6\nv_rcp_f64 %7, %7\n"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+        }
+        if (MODE == 21) {      // v_bfe_u32 + v_cvt: the pair fit_sums issues per table entry
+            asm volatile("v_bfe_u32 %0, %4, 3, 1\nv_bfe_u32 %1, %4, 4, 1\nv_bfe_u32 %2, %4, 5, 1\nv_bfe_u32 %3, %4, 6, 1\n"
+                         "v_lshlrev_b32 %0, 20, %0\nv_lshlrev_b32 %1, 20, %1\nv_lshlrev_b32 %2, 20, %2\nv_lshlrev_b32 %3, 20, %3\n"
+                         : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "v"(ub));
+        }
         if (MODE == 11) {      // v_cndmask with distinct destination registers (no chain through the destination)
             asm volatile("v_cndmask_b32 %0, %8, %9, vcc\nv_cndmask_b32 %1, %8, %9, vcc\nv_cndmask_b32 %2, %8, %9, vcc\nv_cndmask_b32 %3, %8, %9, vcc\n"
                          "v_cndmask_b32 %4, %8, %9, vcc\nv_cndmask_b32 %5, %8, %9, vcc\nv_cndmask_b32 %6, %8, %9, vcc\nv_cndmask_b32 %7, %8, %9, vcc\n"
@@ -173,6 +189,9 @@ int main() {
     run<16>("v_cndmask (old vcc), v_add alternating", dout, sink);
     run<17>("v_cndmask_b32_e64 with vcc", dout, sink);
     run<18>("v_addc_co_u32 chain through vcc", dout, sink);
+    run<19>("v_cvt_f64_u32", dout, sink);
+    run<20>("v_rcp_f64", dout, sink);
+    run<21>("v_bfe_u32 / v_lshlrev_b32", dout, sink);
     run<10>("v_cmp_lt_f64 + v_cndmask_b32 (8 instructions per group)", dout, sink);
     return 0;
 }
