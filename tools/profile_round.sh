@@ -27,7 +27,12 @@ if [ -f narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so ]; then
     NBLS_LIB=narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so python tools/quick_time.py $C 2 lts_stamps=1 2>&1 | grep -v CAUTION | tail -n 4
   done > $OUT/${TAG}_lts_stamps.txt
 fi
+bash tools/pmc_insts.sh 1 > $OUT/${TAG}_insts_per_wave.txt 2>&1
+if [ -f narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so ]; then
+  NBLS_LIB=narrow_band_least_squares_amd/csrc/libnbls_hip_dev.so python tools/quick_time.py cfg3 1 3 lts_stamps=1 2>&1 | grep -v CAUTION | tail -n 4 > $OUT/${TAG}_lts_wave_stamps_cfg3.txt
+fi
 python tools/long_window_time.py 2>&1 | grep -v CAUTION > $OUT/${TAG}_long_window_time.txt
 [ -x tools/lds_atomic_rate ] && ./tools/lds_atomic_rate > $OUT/${TAG}_lds_atomic_rate.txt 2>&1
 [ -x tools/bk_pass_rate ] && ./tools/bk_pass_rate > $OUT/${TAG}_bk_pass_rate.txt 2>&1
+[ -x tools/valu_rate ] && ./tools/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
 ls $OUT
