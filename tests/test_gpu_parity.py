@@ -197,6 +197,22 @@ def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha, nine):
     _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
 
 
+@pytest.mark.parametrize('keep,alpha', [([0, 1, 3, 4], 0.5), ([0, 1, 2, 3, 5], 0.5), ([0, 1, 2, 3, 4, 5], 0.75),
+                                        ([0, 1, 2, 3, 5, 6, 8], 0.5)])
+def test_ltsva_small_regular_grids_take_the_tie_path(oracle, keep, alpha):
+    """4, 5, 6 and 7 elements on a regular grid: equal |r| across position h in every instantiation of the
+    register-resident LTS kernel (subset = the values below the h-th smallest plus the FIRST tied ones in index
+    order; csrc/solve.hip, select_reg)."""
+    fs, npts = 20.0, 5000
+    grid = np.array([(x, y) for x in (0.0, 0.3, 0.6) for y in (0.0, 0.3, 0.6)]).T
+    rij = grid[:, keep]
+    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=rij.shape[1] - 1, seed=11 + len(keep))
+    st = synthetic.make_stream(data, fs)
+    c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=st)
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 4.0, 2, 0.01)
+    _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
+
+
 @pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5), (20, 0.75), (32, 0.5)])
 def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alpha):
     """9..16 elements (36..120 pairs, 500 random starts): the wave-cooperative LTS kernel against the
