@@ -129,6 +129,9 @@ def main():
     ap.add_argument('--band-share', default=None,
                     help='"k/n": run only the k-th of n band shares of the config (default 0/8 for cfg4, all bands otherwise)')
     ap.add_argument('--scale', type=float, default=1.0, help='shorten the trace (debug only; invalidates the metric)')
+    ap.add_argument('--independent-calls', choices=['auto', 'on', 'off'], default='auto',
+                    help='after the main measurement, time one whole single-GPU call per rank on the rank\'s own trace '
+                         '(no collective; extra field `independent_calls`).  auto: in band-sharded runs under a launcher')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-noise', action='store_true')
     args = ap.parse_args()
@@ -460,6 +463,51 @@ def main():
                          'xcorr_screen_ms': float(np.mean([s['screen_ms'] for s in stages_n])),
                          'xcorr_verify_ms': float(np.mean([s['verify_ms'] for s in stages_n])),
                          'input': 'independent white Gaussian noise on every element, same shape and bands'}
+    # The other way to use N GPUs, beside the band-sharded call that `value` measures: every rank runs the WHOLE
+    # single-GPU call on a trace of its own (another array / another stretch of time), no collective.  One call's
+    # strong scaling is bounded by the host work that follows the gather (the dictionary); this is what the same
+    # node delivers on independent traces.  Extra field, never `value`.
+    want_ind = args.independent_calls == 'on' or (args.independent_calls == 'auto' and multi and not shard_traces and td is not None)
+    if want_ind and call_args is not None and not one_process:
+        ind_err, el_i = None, 0.0
+        try:
+            c2 = synthetic.build_config(args.config, scale=args.scale, trace_seed=synthetic.SEED + 101 + rank)
+            st2 = c2['st']
+
+            def solo():
+                planner.design_cache_clear()
+                with contextlib.redirect_stdout(sys.stderr):
+                    return narrow_band_least_squares(*call_args[:3], st2, *call_args[4:], rij=rij)
+            solo()
+        except Exception as e:      # noqa: BLE001
+            ind_err = '%s: %s' % (type(e).__name__, e)
+        barrier()
+        t_i = time.perf_counter()
+        held_i = []
+        if ind_err is None:
+            try:
+                for _ in range(args.steps):
+                    held_i.append(solo())
+            except Exception as e:      # noqa: BLE001
+                ind_err = '%s: %s' % (type(e).__name__, e)
+        barrier()
+        el_i = time.perf_counter() - t_i
+        del held_i
+        bad_i = 1 if ind_err else 0
+        if td is not None:
+            import torch
+            tt = torch.tensor([el_i, float(bad_i)], dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            el_i, bad_i = float(tt[0].item()), int(tt[1].item())
+        if rank == 0:
+            if bad_i:
+                line['independent_calls'] = {'value': None, 'note': 'failed (%s)' % (ind_err or 'on another rank')}
+            else:
+                line['independent_calls'] = {
+                    'value': units_call * ngpu * args.steps / el_i, 'unit': 'solves/s', 'ms_per_step': el_i / args.steps * 1e3,
+                    'n_gpus': ngpu, 'steps': args.steps, 'scaling': 'weak',
+                    'what': 'one whole narrow_band_least_squares() call per rank on the rank\'s own synthetic trace of the same '
+                            'configuration, barrier + max over ranks around the %d calls, no collective in the timed region' % args.steps}
     if rank == 0:
         if not args.no_cpu_baseline and ngpu == 1:
             line['cpu_baseline'] = cpu_baseline(c, edges, winlens)
