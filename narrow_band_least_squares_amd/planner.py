@@ -266,13 +266,20 @@ def uniran_subsets(P, n_samples=LTS_N_SAMPLES, p=LTS_DIM):
     return _uniran_cached(int(P), int(n_samples), int(p)).copy()
 
 
+@functools.lru_cache(maxsize=64)
+def _all_pairs(P):
+    out = np.array([(i, j) for i in range(P - 1) for j in range(i + 1, P)], dtype=np.int64)
+    out.flags.writeable = False
+    return out
+
+
 def lts_starts(xs):
     """Elemental starts on the standardised co-array: every 2-subset if there are at most
     LTS_N_SAMPLES of them, else LTS_N_SAMPLES LCG-random ones; rank-deficient subsets are
     extended until they have rank 2.  (S, 4) int32, -1 padded."""
     P = xs.shape[0]
     if P * (P - 1) // 2 <= LTS_N_SAMPLES:
-        subs = np.array([(i, j) for i in range(P - 1) for j in range(i + 1, P)], dtype=np.int64)
+        subs = _all_pairs(int(P))
     else:
         subs = uniran_subsets(P)
     out = -np.ones((len(subs), 4), dtype=np.int32)
@@ -338,6 +345,19 @@ _REW_500 = [[-0.417574780492848, -0.175753709374146], [1.83958876341367, 1.83138
 _REW_875 = [[-0.267522855927958, -0.161200683014406], [1.17559984533974, 1.21675019853961], [3, 5]]
 
 
+@functools.lru_cache(maxsize=64)
+def _lts_factors(P, alpha):
+    """Consistency and small-sample factors of the raw and the reweighted scale: pure functions of the pair count and
+    alpha (like the LCG subsets above), computed once per (P, alpha) and kept."""
+    h = lts_h(P, alpha)
+    raw = _consfactor(h, P) * _cnp2(LTS_DIM, P, alpha, _RAW_500, _RAW_875)
+    rew = np.ones(P + 1)
+    cor = _cnp2(LTS_DIM, P, alpha, _REW_500, _REW_875)
+    rew[1:P] = _consfactor_table(P) * cor
+    rew.flags.writeable = False
+    return raw, rew
+
+
 def lts_plan(xij, alpha):
     """Everything the LTS kernel needs besides the lags (see ``nbls_lts_params``)."""
     if not (0.5 <= alpha < 1.0):
@@ -348,10 +368,8 @@ def lts_plan(xij, alpha):
     if not np.all(xij_mad > 0):
         raise RuntimeError('Co-array MAD is zero along an axis; cannot standardise for LTS.')
     starts = lts_starts(xij / xij_mad)
-    raw = _consfactor(h, P) * _cnp2(LTS_DIM, P, alpha, _RAW_500, _RAW_875)
-    rew = np.ones(P + 1)
-    cor = _cnp2(LTS_DIM, P, alpha, _REW_500, _REW_875)
-    rew[1:P] = _consfactor_table(P) * cor
+    raw, rew = _lts_factors(int(P), float(alpha))
+    rew = rew.copy()
     return dict(alpha=alpha, h=h, starts=starts, csteps=LTS_CSTEPS, csteps2=LTS_CSTEPS2,
                 ncand=LTS_CANDIDATES, xij_mad=xij_mad, raw_factor=raw, rew_table=rew,
                 quantile=LTS_QUANTILE, zero_scale=LTS_ZERO_SCALE)
