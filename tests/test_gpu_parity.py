@@ -636,6 +636,20 @@ def test_zero_channel_nan_semantics(oracle):
     _compare_ltsva(oracle, c, st_o, 30.0, 1.0)
 
 
+@pytest.mark.parametrize('nchans,alpha', [(8, 0.5), (6, 0.75), (12, 0.5), (24, 0.75)])
+def test_dead_channel_under_lts(oracle, nchans, alpha):
+    """An all-zero element with LTS switched on: its N - 1 pairs carry NaN maxima and the lag of a 0/0 arg-max; the
+    robust fit has to drop them (register kernel: 6 and 8 elements; large-array kernel: 12 and 24) exactly as the
+    oracle does — lags, z, weights, dropped elements, MdCCM by nanmedian."""
+    fs, npts = 20.0, 3600
+    rij = synthetic.array_geometry(nchans, 1.2, seed=70 + nchans)
+    data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, seed=5 + nchans)
+    data[nchans // 2] = 0.0
+    c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=synthetic.make_stream(data, fs))
+    stf_o, _, _ = oracle.filter_data(_ostream(oracle, c), 'butter', 0.5, 4.0, 2, 0.01)
+    _compare_ltsva(oracle, c, stf_o, 30.0, alpha)
+
+
 def test_errors_match_reference_types():
     c = _cfg('cfg1', 0.1)
     with pytest.raises(ValueError):
