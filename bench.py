@@ -435,6 +435,16 @@ def main():
                                  '(sum over the call\'s band groups, HIP events per handle). ALGORITHMIC fraction: 2*P*W^2 flop per unit x units / kernel time, not issued work '
                                  '(the screening kernel issues 3 int8 limb products per multiply-add and skips lag '
                                  'blocks that cannot hold the maximum; see `noise` for the input without coherent signal)'},
+            # the other compute kernel of the path, in the flops SURVEY 8(a11) prices it with (starts x 4 C-steps x 14 P):
+            # what the FAST-LTS kernel delivers against the FP64 VECTOR peak (no matrix cores: 2x2 Gramians).  The honest
+            # bound of this kernel is vector-instruction issue (~41 instructions per pair and selection)
+            'roofline_solve': (None if c['alpha'] >= 1.0 else {
+                'bound': 'fp64_vector', 'unit': 'TFLOP/s', 'peak': FP64_MFMA_PEAK_TFLOPS,
+                'achieved': (min(500, P * (P - 1) // 2) * 4 * 14.0 * P) * units_gpu / (mean('solve_ms') * 1e-3) / 1e12,
+                'frac': (min(500, P * (P - 1) // 2) * 4 * 14.0 * P) * units_gpu / (mean('solve_ms') * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                'kernel': 'solve_lts_wave_kernel (<= 8 elements)' if nchans <= 8 else 'solve_lts_bucket_kernel (9..32 elements)',
+                'kernel_ms_per_step': mean('solve_ms'),
+                'note': 'algorithmic flops of SURVEY 8(a11): starts * 4 * 14 * P per unit; the kernel issues several times that in selection work'}),
             'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_total / (ms_step * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': bytes_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'frac_kernel_only': bytes_total * share_f / (kernel_only * 1e-3) / 1e9 / HBM_PEAK_GBS,
