@@ -55,7 +55,7 @@ def test_cfg2_all_bands_at_its_own_alpha(oracle):
 def test_cfg4_unit_shape_through_the_whole_call(oracle):
     """cfg-4's unit: 16 elements (P = 120, h = 61), 100 Hz, W = 3000 samples, alpha = 0.5, 500 LCG-random starts —
     3 bands x 21 windows through narrow_band_least_squares() against the oracle; lags and weights of one band
-    exactly; the int8 screening correlator and the cooperative LTS kernel are the ones that run."""
+    exactly; the int8 screening correlator and the large-array LTS kernel are the ones that run."""
     c = _cfg('cfg4', 345.0 / 86400.0)
     assert c['N'] == 16 and c['fs'] == 100.0 and c['alpha'] == 0.5
     sub = _sub_config(c, [50, 51, 52])

@@ -186,7 +186,7 @@ def test_ltsva_regular_grid_ties_and_singular_starts(oracle, alpha, nine):
     fs, npts = 20.0, 6000
     rij = np.array([(x, y) for x in (0.0, 0.3, 0.6) for y in (0.0, 0.3, 0.6)]).T
     if not nine:
-        rij = rij[:, [0, 1, 2, 3, 5, 6, 7, 8]]      # 8 elements: register kernel; 9: the cooperative kernel
+        rij = rij[:, [0, 1, 2, 3, 5, 6, 7, 8]]      # 8 elements: register kernel; 9: the large-array kernel
     data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=rij.shape[1] - 1, seed=7)
     st = synthetic.make_stream(data, fs)
     c = dict(rij=rij - rij.mean(axis=1, keepdims=True), fs=fs, data=data, st=st)
@@ -214,9 +214,10 @@ def test_ltsva_small_regular_grids_take_the_tie_path(oracle, keep, alpha):
 
 
 @pytest.mark.parametrize('nchans,alpha', [(9, 0.5), (12, 0.75), (16, 0.5), (20, 0.75), (32, 0.5)])
-def test_ltsva_large_arrays_cooperative_kernel(oracle, monkeypatch, nchans, alpha):
-    """9..16 elements (36..120 pairs, 500 random starts): the wave-cooperative LTS kernel against the
-    oracle, and against the generic lane-per-start kernel (option "lts_impl" = 1) bit for bit."""
+def test_ltsva_large_arrays_bucket_kernel(oracle, monkeypatch, nchans, alpha):
+    """9..32 elements (36..496 pairs, 500 random starts): the large-array LTS kernel (solve_bucket.inc; VERDICT r02
+    calls this test ..._cooperative_kernel after the kernel it replaced) against the oracle, and against the generic
+    lane-per-start kernel (option "lts_impl" = 1) bit for bit."""
     fs, npts = 20.0, 3000
     rij = synthetic.array_geometry(nchans, 1.5)
     data = synthetic.plane_wave(rij, npts, fs, 0.5, 4.0, timing_error_s=0.25, bad_element=nchans - 1, seed=11)

@@ -59,7 +59,7 @@ def main():
         tot = st['total'] or 1.0
         print('lts stamps (mean cycles per wave):', {k: '%.0f (%.0f%%)' % (v, 100 * v / tot) for k, v in st.items()})
         if len(rows) > 8:
-            print('cooperative kernel, C-step phase (thread 0 cycles):', {k: '%.0f' % v for k, v in h.lts_coop_breakdown().items()})
+            print('large-array LTS kernel, C-step phase (thread 0 cycles):', {k: '%.0f' % v for k, v in h.lts_coop_breakdown().items()})
     out = h.fetch_packed()
     mid = nb // 2
     n = int(prep.nwin[mid])

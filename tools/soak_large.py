@@ -1,4 +1,4 @@
-"""Developer: one-off soak of ltsva() with 9..24 elements (the cooperative FAST-LTS kernel, partner-group screening)
+"""Developer: one-off soak of ltsva() with 9..24 elements (the large-array FAST-LTS kernel, partner-group screening)
 against the oracle: lags, weights, z exactly / to 1e-9.    python tools/soak_large.py FIRST LAST [NLO NHI]
 (NLO NHI = 24 33: the u16-counter / no-merging form of the large-array LTS kernel, more than 255 pairs)"""
 import os, sys
