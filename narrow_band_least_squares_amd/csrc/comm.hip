@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types and prototypes only: every call goes through the table below
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -52,10 +53,12 @@ int cfail(nbls_handle* h, int code, const std::string& msg) {
 RcclApi* rccl(std::string* why) {
     std::lock_guard<std::mutex> l(g_mu);
     if (g_api.lib) return &g_api;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // NBLS_RCCL_LIB: another library with the same ten entry points, tried first (the tests use a loopback stand-in
+    // to run several ranks of ONE process on one GPU: tests/c_caller/loopback_rccl.cpp)
+    const char* names[] = {getenv("NBLS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* lib = nullptr;
     for (const char* n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!lib) {
         if (why) *why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "");
         return nullptr;
@@ -150,8 +153,11 @@ int nbls_comm_init_all(nbls_handle* const* hs, int32_t n) {
     for (int i = 0; i < n; ++i) {
         (void)nbls_comm_destroy(hs[i]);
         devs[i] = hs[i]->device;
+        // (RCCL itself refuses a device twice; NBLS_ALLOW_SHARED_DEVICE=1 is for the loopback stand-in of the tests)
+        const char* shared = getenv("NBLS_ALLOW_SHARED_DEVICE");
         for (int j = 0; j < i; ++j)
-            if (devs[j] == devs[i]) return cfail(hs[0], NBLS_ERR_ARG, "nbls_comm_init_all: two handles on the same device");
+            if (devs[j] == devs[i] && !(shared && shared[0] == '1'))
+                return cfail(hs[0], NBLS_ERR_ARG, "nbls_comm_init_all: two handles on the same device");
     }
     std::vector<ncclComm_t> comms(n, nullptr);
     NCCLC(hs[0], api, api->CommInitAll(comms.data(), n, devs.data()));

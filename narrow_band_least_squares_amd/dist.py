@@ -147,7 +147,12 @@ def get_group():
     key = ('all', tuple(devs), os.getpid())
     g = _groups.get(key)
     if g is None:
-        hs = [engine.get_handle(d) for d in devs]
+        seen = {}
+        hs = []
+        for d in devs:                               # (a device listed twice — loopback rehearsal on one GPU — gets two handles)
+            k = seen.get(d, 0)
+            seen[d] = k + 1
+            hs.append(engine.get_handle(d, k))
         arr = (C.c_void_p * len(hs))(*[h._h for h in hs])
         hs[0]._chk(hs[0].lib.nbls_comm_init_all(arr, len(hs)))
         g = Group(hs, list(range(len(hs))), len(hs), root=0)

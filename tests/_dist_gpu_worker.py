@@ -3,7 +3,14 @@ Runs in its own process because a communicator, once made, lives as long as the 
 
   mode 'all'   one process drives every visible GPU (this box: one): ncclCommInitAll + gather to root 0
   mode 'rank'  process-per-GPU form with a one-rank world: the 128-byte id, ncclCommInitRank, all-gather
-Both must equal the serial call bit for bit, bands- and windows-sharded."""
+  mode 'loopN' (N = 2, 3): N RANKS of one process on this box's one GPU — N library handles, N launch threads, N result
+               blocks in HBM, nbls_comm_gather with root 0 — over the loopback stand-in of tests/c_caller/loopback_rccl.cpp
+               (device-to-device copies where RCCL would use xGMI; the caller set NBLS_RCCL_LIB, NBLS_ALLOW_SHARED_DEVICE,
+               NBLS_DEVICES=0,0[,0])
+  mode 'proc'  one PROCESS per rank under a launcher (python -m torch.distributed.run --nproc-per-node 2 ...), all of them
+               on this box's one GPU (NBLS_DEVICE=0): the id over the TCP side channel, ncclCommInitRank with a world of
+               two, the all-gather — the stand-in moves the blocks through shared host memory
+All must equal the serial call bit for bit, bands- and windows-sharded."""
 import os
 import sys
 
@@ -56,7 +63,13 @@ def main():
             for k in ser[4]:
                 np.testing.assert_array_equal(par[4][k], ser[4][k])
     g = dist.get_group()
-    assert g is not None and g.world == 1 and g.handles[0].lib.nbls_version() >= 200
+    want_world = int(mode[4:]) if mode.startswith('loop') else 1
+    if mode == 'proc':
+        assert int(os.environ['WORLD_SIZE']) > 1 and g.world == int(os.environ['WORLD_SIZE']) and len(g.handles) == 1
+        print('DIST_GPU_OK', mode, 'rank', os.environ['RANK'], flush=True)
+        return
+    assert g is not None and g.world == want_world and len(g.handles) == want_world and g.handles[0].lib.nbls_version() >= 200
+    assert len({id(h) for h in g.handles}) == want_world
     assert 'torch' not in sys.modules
     print('DIST_GPU_OK', mode)
 

@@ -547,6 +547,96 @@ def test_band_sharded_entry_point_under_rccl(mode):
     assert r.returncode == 0 and 'DIST_GPU_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def _loopback_env():
+    """Environment of a process whose ranks are several handles on this box's one GPU, with the loopback stand-in
+    (tests/c_caller/loopback_rccl.cpp, built here with hipcc) where RCCL would be."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'tests', 'c_caller', 'loopback_rccl.cpp')
+    lib = os.path.join(root, 'tests', 'c_caller', 'libloopback_rccl.so')
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.run(['/opt/rocm/bin/hipcc', '-O2', '-shared', '-fPIC', '--offload-arch=gfx950', src, '-o', lib], check=True, timeout=300)
+    env = dict(os.environ)
+    env.update(NBLS_RCCL_LIB=lib, NBLS_ALLOW_SHARED_DEVICE='1')
+    return root, env
+
+
+@pytest.mark.parametrize('nranks', [2, 3])
+def test_several_ranks_of_one_process_on_one_gpu_over_a_loopback_transport(nranks):
+    """What a one-GPU box can run of the multi-rank path: narrow_band_least_squares_parallel() with 2 and 3 ranks of ONE
+    process (a handle, a launch thread and a result block in HBM per rank; LPT band shares and window slices; a share in
+    several HBM rounds), nbls_comm_gather with its status words to root 0, the root's assembly — the blocks moved by a
+    loopback stand-in instead of RCCL.  Equal to the serial call bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root, env = _loopback_env()
+    env['NBLS_DEVICES'] = ','.join(['0'] * nranks)
+    cmd = [sys.executable, os.path.join(root, 'tests', '_dist_gpu_worker.py'), 'loop%d' % nranks]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'DIST_GPU_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_drives_two_ranks_without_a_launcher_over_the_loopback_transport():
+    """`python bench.py --gpus 2` exactly as the driver starts it (no launcher): the one-process form, here with both
+    ranks on this box's one GPU and the loopback stand-in — a functional rehearsal of the bench's multi-GPU code path
+    (its numbers mean nothing: two ranks share one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root, env = _loopback_env()
+    env['NBLS_DEVICES'] = '0,0'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'cfg2', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--no-noise']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] and line['value'] > 0
+    assert 'one process drives all of them' in line['config']['parallelism']
+
+
+def _launch_two_ranks(script_args, env, port, timeout=600):
+    import subprocess
+    import sys
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port)] + script_args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_one_process_per_rank_under_the_launcher_on_one_gpu_over_the_loopback_transport():
+    """The launcher form the driver uses for its scaling runs, rehearsed with two ranks on this box's one GPU: RANK /
+    WORLD_SIZE from torch.distributed.run, the communicator id over the TCP side channel, ncclCommInitRank, every rank
+    computes its band share (or window slice) and the all-gather returns the complete result on every rank — equal to
+    the serial call bit for bit on both.  (Stand-in transport: shared host memory.)"""
+    import os
+    root, env = _loopback_env()
+    env['NBLS_DEVICE'] = '0'
+    r = _launch_two_ranks([os.path.join(root, 'tests', '_dist_gpu_worker.py'), 'proc'], env, 29741)
+    assert r.returncode == 0 and r.stdout.count('DIST_GPU_OK proc') == 2, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_under_the_launcher_with_two_ranks_over_the_loopback_transport():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` — the command line of the driver's
+    scaling run — with both ranks on this box's one GPU: barrier / max-over-ranks (gloo), the band-sharded whole call,
+    the `independent_calls` leg, ONE JSON line from rank 0.  Functional rehearsal; the numbers mean nothing."""
+    import json
+    import os
+    root, env = _loopback_env()
+    env['NBLS_DEVICE'] = '0'
+    r = _launch_two_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'cfg2', '--steps', '2', '--warmup', '1',
+                           '--no-noise'], env, 29743)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] and line['value'] > 0
+    assert 'one process per GPU' in line['config']['parallelism']
+    ind = line['independent_calls']
+    assert ind['scaling'] == 'weak' and ind['n_gpus'] == 2 and ind['value'] > 0
+
+
 @pytest.mark.parametrize('alpha', [0.75, 1.0])
 def test_zero_edit_drop_in_route_with_lat_lon(oracle, tmp_path, alpha):
     """north_star: "drops into example.py".  tests/_dropin_script.py is written like the reference's script — its import
