@@ -7,6 +7,7 @@ Runs in its own process because a communicator, once made, lives as long as the 
                blocks in HBM, nbls_comm_gather with root 0 — over the loopback stand-in of tests/c_caller/loopback_rccl.cpp
                (device-to-device copies where RCCL would use xGMI; the caller set NBLS_RCCL_LIB, NBLS_ALLOW_SHARED_DEVICE,
                NBLS_DEVICES=0,0[,0])
+  mode 'procfail'  the same launcher form, with rank 1 failing before it can plan (status word, nobody hangs), then a healthy call
   mode 'proc'  one PROCESS per rank under a launcher (python -m torch.distributed.run --nproc-per-node 2 ...), all of them
                on this box's one GPU (NBLS_DEVICE=0): the id over the TCP side channel, ncclCommInitRank with a world of
                two, the all-gather — the stand-in moves the blocks through shared host memory
@@ -34,6 +35,34 @@ def main():
         assert h.lib.nbls_comm_unique_id(uid, 128) == 0
         h._chk(h.lib.nbls_comm_init_rank(h._h, bytes(uid), 1, 0))
         dist._group_override = dist.Group([h], [0], 1, root=-1)
+    if mode == 'procfail':
+        # rank 1 fails before it can plan: it must still enter the gather (an empty block, status word set), rank 0 must
+        # learn of it from the status word, nobody may hang — and the communicator must serve a healthy call afterwards
+        rank = int(os.environ['RANK'])
+        c = synthetic.build_config('cfg2', 0.1)
+        fr = np.logspace(-2, 1, 40)
+        w = np.zeros(40)
+        args = (c['WINLEN_list'][:5], 0.5, 0.5, c['st'], None, None, 5, w, w, c['freqlist'][:6], c['band_type'], fr, 'butter', 2, 0.01)
+        real_prepare = engine.prepare
+        if rank == 1:
+            def broken(*a, **k):
+                raise MemoryError('injected failure on rank 1')
+            engine.prepare = broken
+        try:
+            narrow_band_least_squares_parallel(*args, rij=c['rij'])
+            raise SystemExit('rank %d: the failed call returned' % rank)
+        except MemoryError as e:
+            assert rank == 1 and 'injected' in str(e)
+        except RuntimeError as e:
+            assert rank == 0 and 'rank(s) [1] failed' in str(e), str(e)
+        engine.prepare = real_prepare
+        par = narrow_band_least_squares_parallel(*args, rij=c['rij'])
+        ser = narrow_band_least_squares(*args, rij=c['rij'])
+        for i in (0, 1, 2, 3, 5, 7, 8):
+            np.testing.assert_array_equal(par[i], ser[i])
+        assert list(par[4].keys()) == list(ser[4].keys())
+        print('DIST_GPU_OK', mode, 'rank', rank, flush=True)
+        return
     # (the fourth case: an HBM budget of two bands per pass — the share runs in three rounds, the block assembled on the
     #  host goes back through nbls_load_result_block and out through the same gather)
     for name, alpha, shard, per_pass in (('cfg1', 1.0, 'bands', 0), ('cfg2', 0.5, 'bands', 0), ('cfg2', 0.75, 'windows', 0),

@@ -617,6 +617,17 @@ def test_one_process_per_rank_under_the_launcher_on_one_gpu_over_the_loopback_tr
     assert r.returncode == 0 and r.stdout.count('DIST_GPU_OK proc') == 2, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_a_rank_that_fails_before_planning_does_not_hang_its_peer_on_hardware():
+    """Launcher form, two ranks on this box's one GPU: rank 1 raises before it can plan.  It still takes part in the
+    gather with an empty block whose status word is set (csrc/comm.hip), rank 0 raises "rank(s) [1] failed", and the
+    next call on the same communicator is healthy and equal to the serial call."""
+    import os
+    root, env = _loopback_env()
+    env['NBLS_DEVICE'] = '0'
+    r = _launch_two_ranks([os.path.join(root, 'tests', '_dist_gpu_worker.py'), 'procfail'], env, 29747, timeout=300)
+    assert r.returncode == 0 and r.stdout.count('DIST_GPU_OK procfail') == 2, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_bench_under_the_launcher_with_two_ranks_over_the_loopback_transport():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` — the command line of the driver's
     scaling run — with both ranks on this box's one GPU: barrier / max-over-ranks (gloo), the band-sharded whole call,
