@@ -227,7 +227,11 @@ int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes);
  *       (all-gather: every process) receives host_out[world][block_bytes]; other processes may pass NULL.
  *       The operation is ordered on the handles' streams after their nbls_execute and returns after the
  *       copy to the host has finished.
- *   nbls_comm_destroy(h)            release the communicator (also done by nbls_destroy)           */
+ *   nbls_comm_destroy(h)            release the communicator (also done by nbls_destroy)
+ * RCCL is resolved with dlopen at the first of these calls (librccl.so.1, librccl.so, /opt/rocm/lib/...).
+ * Environment, for rehearsals on a one-GPU box only: NBLS_RCCL_LIB names a library with the same ten entry
+ * points to try first (tests/c_caller/loopback_rccl.cpp), NBLS_ALLOW_SHARED_DEVICE=1 lets nbls_comm_init_all
+ * take several handles of one device.                                                              */
 int nbls_comm_init_all(nbls_handle* const* hs, int32_t n);
 int nbls_comm_unique_id(void* id, int32_t nbytes);
 int nbls_comm_init_rank(nbls_handle* h, const void* id, int32_t world, int32_t rank);
