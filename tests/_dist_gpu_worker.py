@@ -69,7 +69,7 @@ def main():
                                          ('cfg2', 0.5, 'bands', 2)):
         os.environ['NBLS_SHARD'] = shard
         c = synthetic.build_config(name, 0.1)
-        nb = 5
+        nb = 9 if mode == 'loop8' else 5             # (eight ranks: some take two bands, most one)
         os.environ.pop('NBLS_MAX_FILTERED_GB', None)
         if per_pass:
             nchans, npts = c['data'].shape

@@ -562,9 +562,9 @@ def _loopback_env():
     return root, env
 
 
-@pytest.mark.parametrize('nranks', [2, 3])
+@pytest.mark.parametrize('nranks', [2, 3, 8])
 def test_several_ranks_of_one_process_on_one_gpu_over_a_loopback_transport(nranks):
-    """What a one-GPU box can run of the multi-rank path: narrow_band_least_squares_parallel() with 2 and 3 ranks of ONE
+    """What a one-GPU box can run of the multi-rank path: narrow_band_least_squares_parallel() with 2, 3 and 8 ranks of ONE
     process (a handle, a launch thread and a result block in HBM per rank; LPT band shares and window slices; a share in
     several HBM rounds), nbls_comm_gather with its status words to root 0, the root's assembly — the blocks moved by a
     loopback stand-in instead of RCCL.  Equal to the serial call bit for bit."""
