@@ -264,7 +264,7 @@ def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
     h.set_profiling(True)
     try:
         got = engine.process(data, fs, 17884.0729166667, rij - rij.mean(axis=1, keepdims=True), edges, winlens, 0.5, 1.0, 'butter', 2, 0.01,
-                             want_lag=True)
+                             want_lag=True, groups=1)          # ONE plan with all five bands, whatever NBLS_PIPELINE_GROUPS says
         tm = h.timings()
         assert tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 1
     finally:
@@ -339,9 +339,10 @@ def test_filter_data_against_the_references_own_output():
     np.testing.assert_array_equal(np.array([tr.data for tr in st]), g['data'])         # the input stream is not modified
 
 
-def test_result_block_stays_contiguous_across_plans():
+def test_result_block_stays_contiguous_across_plans(monkeypatch):
     """A smaller plan after a bigger one keeps the allocation but must move the grid views: vel | baz | mdccm |
     sigma_tau are always back to back (one D2H copy / one RCCL block), and the values are those of a fresh handle."""
+    monkeypatch.setenv('NBLS_PIPELINE_GROUPS', '1')         # the plans under test are those of handle 0 with ALL bands
     c = _cfg('cfg1', 0.3)
     fr = np.logspace(-2, 1, 16)
     w = np.zeros(16)

@@ -814,12 +814,13 @@ def _full_size_properties(c, edges, winlens, nchans_bad, subset, broadband, chec
     data, fs, t0 = engine.stream_to_array(c['st'])
     kw = dict(groups=1)
     r1 = engine.process(data, fs, t0, c['rij'], edges, winlens, 0.5, 0.5, 'butter', 2, 0.01, **kw)
+    filt_tail = r1.handle.fetch_filtered(check_tail_band) if check_tail_band is not None else None
     n = r1.nwin.astype(int)
     tail = None
     if check_tail_band is not None:
         b = check_tail_band
-        h = r1.handle
-        filt = h.fetch_filtered(b)                                   # (N, npts) filtered + tapered band, as the device holds it
+        filt = filt_tail                                             # (N, npts) filtered + tapered band, as the device holds it
+        filt_tail = None
         W, inc = int(r1.W[b]), int(r1.inc[b])
         s0 = (n[b] - 3) * inc
         tail = np.ascontiguousarray(filt[:, s0:s0 + 2 * inc + W + 1])
@@ -856,10 +857,11 @@ def _full_size_properties(c, edges, winlens, nchans_bad, subset, broadband, chec
     return r1
 
 
-def test_full_size_cfg4_share_properties():
+def test_full_size_cfg4_share_properties(monkeypatch):
     """BASELINE configs[3] at full size, ONE GPU's share: band share 0 of 8 (12 of the 96 bands, the LPT partition of
     narrow_band_least_squares_parallel) of the 16-element, 24 h @ 100 Hz trace — 69 096 units, 120 pairs, 500 LCG
     starts, W = 3000."""
+    monkeypatch.delenv('NBLS_MAX_FILTERED_GB', raising=False)     # ONE in-core pass holds all bands (the tail check reads one back)
     from narrow_band_least_squares_amd import dist
     c = _cfg('cfg4', 1.0)
     costs = dist.band_costs(c['npts'], c['fs'], list(c['WINLEN_list']), c['overlap'], 120)
@@ -871,9 +873,10 @@ def test_full_size_cfg4_share_properties():
     assert int(r.nwin.sum()) == 69096
 
 
-def test_full_size_cfg5_properties():
+def test_full_size_cfg5_properties(monkeypatch):
     """BASELINE configs[4] at full size: 32 elements (496 pairs, 500 LCG starts), all 128 bands, 1 h @ 20 Hz — 30 464
     units in one call (band prefixes beyond '99_' included in the dictionary path elsewhere)."""
+    monkeypatch.delenv('NBLS_MAX_FILTERED_GB', raising=False)
     c = _cfg('cfg5', 1.0)
     edges = [(c['freqlist'][i], c['freqlist'][i + 1]) for i in range(c['NBANDS'])]
     r = _full_size_properties(c, edges, list(c['WINLEN_list']), 31, [3, 64, 127], (0.3, 3.0), check_tail_band=127)
