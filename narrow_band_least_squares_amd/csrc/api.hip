@@ -68,7 +68,16 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
     // must not wait behind them — on a low-priority compute stream the ~15 small copies of a plan took 5 ms instead
     // of 0.3); nbls_plan / nbls_set_geometry wait for that stream before they return (StreamGuard), i.e. before the
     // host buffers go away and before any kernel that reads the tables can be launched
-    if (n) HIPCHK(h, hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->up));
+    if (n) {
+        const size_t bytes = n * sizeof(T), slot = (bytes + 63) & ~(size_t)63;
+        const void* from = src;
+        if (h->stage && h->stage_used + slot <= h->stage_cap) {      // through the pinned arena (reset by StreamGuard)
+            memcpy(h->stage + h->stage_used, src, bytes);
+            from = h->stage + h->stage_used;
+            h->stage_used += slot;
+        }
+        HIPCHK(h, hipMemcpyAsync(*p, from, bytes, hipMemcpyHostToDevice, h->up));
+    }
     return 0;
 }
 
@@ -84,6 +93,13 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
 struct StreamGuard {
     nbls_handle* h;
     explicit StreamGuard(nbls_handle* hh) : h(hh) {
+        // the staging arena of alloc_copy: everything queued from it has been read when the previous guard left
+        if (!h->stage) {
+            constexpr size_t kStage = (size_t)8 << 20;
+            if (hipHostMalloc((void**)&h->stage, kStage, hipHostMallocDefault) == hipSuccess) h->stage_cap = kStage;
+            else { h->stage = nullptr; h->stage_cap = 0; (void)hipGetLastError(); }
+        }
+        h->stage_used = 0;
         if (h->up != h->stream && h->ev_plan) {
             for (hipStream_t s : {h->stream, h->stream2}) {
                 if (!s) continue;
@@ -230,6 +246,7 @@ void nbls_destroy(nbls_handle* h) {
     if (h->up && h->up != h->stream) (void)hipStreamDestroy(h->up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stage) (void)hipHostFree(h->stage);
     delete h;
 }
 

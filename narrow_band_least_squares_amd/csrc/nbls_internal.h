@@ -136,6 +136,11 @@ struct nbls_handle {
     uint8_t* d_wts = nullptr;      // [B][VL][P] one byte per pair (kernel-side form; packed into d_mask after the solve)
     size_t cap_filt = 0, cap_cstate = 0, cap_lag = 0, cap_cmax = 0, cap_z = 0, cap_wts = 0;
     std::unordered_map<const void*, size_t> caps;   // capacities of the small plan tables, keyed by the address of the pointer member
+    // pinned staging of the plan tables (api.hip: alloc_copy): a copy from pinned memory goes through the DMA engines,
+    // a copy from pageable memory is a shader copy that has to find a free CU — with three other band groups of the
+    // call filling the GPU each of a plan's ~25 small uploads took ~60 us instead of ~5
+    unsigned char* stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
 
     // ---- int8 screening correlator (xcorr_screen.hip) ----
     int8_t* d_qbuf = nullptr;      // [batch][N][2][WP]
