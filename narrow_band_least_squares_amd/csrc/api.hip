@@ -371,13 +371,24 @@ int nbls_set_geometry(nbls_handle* h, const double* xij, const int32_t* pair_idx
     const double det = sxx * syy - sxy * sxy;
     if (!(det > 1e-12 * (sxx + syy) * (sxx + syy)))
         return fail(h, NBLS_ERR_GEOMETRY, "co-array is rank deficient (collinear array)");
+    // the same geometry as the handle already holds (every band group of every call of one array): nothing to upload
+    const size_t n2 = (size_t)npairs * 2;
+    if (h->d_xij && h->d_pair && h->d_xpinv && h->npairs == npairs && h->h_xij.size() == n2 && h->h_pair.size() == n2 &&
+        h->h_xpinv.size() == n2 && memcmp(h->h_xij.data(), xij, n2 * sizeof(double)) == 0 &&
+        memcmp(h->h_pair.data(), pair_idx, n2 * sizeof(int32_t)) == 0 && memcmp(h->h_xpinv.data(), xpinv, n2 * sizeof(double)) == 0) {
+        h->planned = false;
+        return NBLS_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     StreamGuard guard(h);
     int rc;
-    if ((rc = alloc_copy(h, &h->d_xij, xij, (size_t)npairs * 2))) return rc;
-    if ((rc = alloc_copy(h, &h->d_pair, pair_idx, (size_t)npairs * 2))) return rc;
-    if ((rc = alloc_copy(h, &h->d_xpinv, xpinv, (size_t)npairs * 2))) return rc;
-    h->h_xij.assign(xij, xij + 2 * npairs);
+    h->h_xij.clear();                        // (a failed upload leaves no stale "already there" record)
+    if ((rc = alloc_copy(h, &h->d_xij, xij, n2))) return rc;
+    if ((rc = alloc_copy(h, &h->d_pair, pair_idx, n2))) return rc;
+    if ((rc = alloc_copy(h, &h->d_xpinv, xpinv, n2))) return rc;
+    h->h_xij.assign(xij, xij + n2);
+    h->h_pair.assign(pair_idx, pair_idx + n2);
+    h->h_xpinv.assign(xpinv, xpinv + n2);
     h->npairs = npairs;
     h->planned = false;
     return NBLS_OK;

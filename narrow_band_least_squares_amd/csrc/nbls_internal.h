@@ -77,6 +77,8 @@ struct nbls_handle {
     int32_t* d_pair = nullptr;     // [P][2]
     double* d_xpinv = nullptr;     // [2][P]
     std::vector<double> h_xij;
+    std::vector<int32_t> h_pair;   // host copies of the other two geometry tables: an identical nbls_set_geometry uploads nothing
+    std::vector<double> h_xpinv;
 
     // ---- plan ----
     bool planned = false;
