@@ -75,6 +75,8 @@ int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
             memcpy(h->stage + h->stage_used, src, bytes);
             from = h->stage + h->stage_used;
             h->stage_used += slot;
+        } else {
+            h->stage_bypass = true;                                  // the caller's buffer is read: the guard has to wait
         }
         HIPCHK(h, hipMemcpyAsync(*p, from, bytes, hipMemcpyHostToDevice, h->up));
     }
@@ -99,7 +101,10 @@ struct StreamGuard {
             if (hipHostMalloc((void**)&h->stage, kStage, hipHostMallocDefault) == hipSuccess) h->stage_cap = kStage;
             else { h->stage = nullptr; h->stage_cap = 0; (void)hipGetLastError(); }
         }
+        if (h->up_pending) { (void)hipStreamSynchronize(h->up); h->up_pending = false; }     // the arena is free again
         h->stage_used = 0;
+        h->stage_bypass = false;
+        if (!h->ev_up && hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) { h->ev_up = nullptr; (void)hipGetLastError(); }
         if (h->up != h->stream && h->ev_plan) {
             for (hipStream_t s : {h->stream, h->stream2}) {
                 if (!s) continue;
@@ -107,8 +112,20 @@ struct StreamGuard {
             }
         }
     }
-    ~StreamGuard() { (void)hipStreamSynchronize(h->up); }
+    ~StreamGuard() {
+        // everything came from the arena: nothing of the caller's is still being read, and the kernels that need the
+        // tables are ordered behind ev_up on the GPU (wait_uploads) — the host does not wait for the copies
+        if (!h->stage_bypass && h->stage && h->ev_up && hipEventRecord(h->ev_up, h->up) == hipSuccess) { h->up_pending = true; return; }
+        (void)hipStreamSynchronize(h->up);
+    }
 };
+
+// GPU-side: the handle's compute streams wait for the plan / geometry tables still on their way (see ev_up).
+void wait_uploads(nbls_handle* h) {
+    if (!h->up_pending || !h->ev_up) return;
+    for (hipStream_t s : {h->stream, h->stream2})
+        if (s && s != h->up) (void)hipStreamWaitEvent(s, h->ev_up, 0);
+}
 
 void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
     constexpr int DM = 2 * NBLS_MAX_SECTIONS;
@@ -232,6 +249,7 @@ void nbls_destroy(nbls_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->up) (void)hipStreamSynchronize(h->up);
     (void)nbls_comm_destroy(h);
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
@@ -243,6 +261,7 @@ void nbls_destroy(nbls_handle* h) {
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->ev_xd) (void)hipEventDestroy(h->ev_xd);
     if (h->ev_plan) (void)hipEventDestroy(h->ev_plan);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->up && h->up != h->stream) (void)hipStreamDestroy(h->up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -509,8 +528,19 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if (nsections == 0 && nbands != 1)
         return fail(h, NBLS_ERR_ARG, "nbls_plan: an unfiltered plan has exactly one band");
     if ((rc = alloc_copy(h, &h->d_M, M.data(), M.size()))) return rc;
-    if ((rc = alloc_copy(h, &h->d_tl, taper_left, (size_t)taper_len))) return rc;
-    if ((rc = alloc_copy(h, &h->d_tr, taper_right, (size_t)taper_len))) return rc;
+    {   // the ramps (5 % of the trace each: 0.7 MB at cfg-3, most of a plan's upload) only when they differ from what is there
+        const size_t tn = (size_t)taper_len;
+        const bool same = h->d_tl && h->d_tr && h->h_tl.size() == tn && h->h_tr.size() == tn &&
+                          (tn == 0 || (memcmp(h->h_tl.data(), taper_left, tn * sizeof(double)) == 0 &&
+                                       memcmp(h->h_tr.data(), taper_right, tn * sizeof(double)) == 0));
+        if (!same) {
+            h->h_tl.clear();
+            h->h_tr.clear();
+            if ((rc = alloc_copy(h, &h->d_tl, taper_left, tn))) return rc;
+            if ((rc = alloc_copy(h, &h->d_tr, taper_right, tn))) return rc;
+            if (tn) { h->h_tl.assign(taper_left, taper_left + tn); h->h_tr.assign(taper_right, taper_right + tn); }
+        }
+    }
     if ((rc = alloc_copy(h, &h->d_W, h->W.data(), (size_t)nbands))) return rc;
     if ((rc = alloc_copy(h, &h->d_inc, h->inc.data(), (size_t)nbands))) return rc;
     if ((rc = alloc_copy(h, &h->d_nwin, h->nwin.data(), (size_t)nbands))) return rc;
@@ -662,6 +692,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if ((stage_mask & 6) && !h->d_xij) return fail(h, NBLS_ERR_STATE, "nbls_execute: no geometry set");
     if (!h->trace_loaded) return fail(h, NBLS_ERR_STATE, "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
+    wait_uploads(h);
     const size_t cells = (size_t)h->nbands * h->vector_len;
     const int P = h->d_xij ? h->npairs : 1;
     // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272)
@@ -773,6 +804,7 @@ int nbls_filter_segment(nbls_handle* h, int32_t reverse, const double* state_in,
     if (reverse && state_in && (h->npts % NBLS_FILTER_CHUNK) != 0)
         return fail(h, NBLS_ERR_ARG, "nbls_filter_segment: a backward segment that continues a state must be a whole number of 512-sample chunks");
     HIPCHK(h, hipSetDevice(h->device));
+    wait_uploads(h);
     const size_t n = (size_t)h->nbands * h->nchans * 2 * h->nsections;
     int rc;
     if ((rc = ensure(h, &h->d_seg_state, &h->cap_seg_state, 2 * n * sizeof(double)))) return rc;

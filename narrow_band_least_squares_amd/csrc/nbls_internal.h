@@ -77,6 +77,7 @@ struct nbls_handle {
     int32_t* d_pair = nullptr;     // [P][2]
     double* d_xpinv = nullptr;     // [2][P]
     std::vector<double> h_xij;
+    std::vector<double> h_tl, h_tr;   // host copies of the taper ramps (the same for every band group and call of one trace length: uploaded once)
     std::vector<int32_t> h_pair;   // host copies of the other two geometry tables: an identical nbls_set_geometry uploads nothing
     std::vector<double> h_xpinv;
 
@@ -143,6 +144,11 @@ struct nbls_handle {
     // call filling the GPU each of a plan's ~25 small uploads took ~60 us instead of ~5
     unsigned char* stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
+    // a plan whose tables all went through the arena does not wait for their copies: the upload stream records ev_up,
+    // and whatever launches kernels that read the tables (nbls_execute*, nbls_filter_segment) makes its streams wait
+    // for it on the GPU; the next plan / geometry call waits for the upload stream before it reuses the arena
+    hipEvent_t ev_up = nullptr;
+    bool up_pending = false, stage_bypass = false;
 
     // ---- int8 screening correlator (xcorr_screen.hip) ----
     int8_t* d_qbuf = nullptr;      // [batch][N][2][WP]
