@@ -35,7 +35,9 @@ int fail(nbls_handle* h, int code, const std::string& msg) {
 hipError_t copy_sync(nbls_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
     if (e != hipSuccess) return e;
-    return hipStreamSynchronize(h->stream);
+    e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) h->work_queued = false;       // (the solve stream is joined into this one at the end of a pass)
+    return e;
 }
 
 template <typename T>
@@ -58,6 +60,20 @@ int ensure(nbls_handle* h, T** p, size_t* cap, size_t need_bytes) {
 template <typename T>
 int alloc_copy(nbls_handle* h, T** p, const T* src, size_t n) {
     const size_t need = (n ? n : 1) * sizeof(T);
+    const bool owned = h->arena_owned.count((const void*)p) != 0;
+    {
+        const size_t slot = (need + 63) & ~(size_t)63;
+        if (h->arena_mode && h->stage && h->d_parena && h->stage_used + slot <= h->stage_cap) {
+            // a table of nbls_plan: a place in the arena, no copy of its own (StreamGuard sends the arena in one piece)
+            if (*p && !owned) { (void)hipFree(*p); h->caps.erase((const void*)p); }
+            if (n) memcpy(h->stage + h->stage_used, src, n * sizeof(T));
+            *p = (T*)(h->d_parena + h->stage_used);
+            h->stage_used += slot;
+            h->arena_owned.insert((const void*)p);
+            return 0;
+        }
+    }
+    if (owned) { *p = nullptr; h->arena_owned.erase((const void*)p); h->caps[(const void*)p] = 0; }   // back to an allocation of its own
     size_t& cap = h->caps[(const void*)p];
     if (!*p || cap < need) {
         if (*p) { (void)hipFree(*p); *p = nullptr; cap = 0; }
@@ -104,8 +120,9 @@ struct StreamGuard {
         if (h->up_pending) { (void)hipStreamSynchronize(h->up); h->up_pending = false; }     // the arena is free again
         h->stage_used = 0;
         h->stage_bypass = false;
+        if (h->stage && !h->d_parena && hipMalloc((void**)&h->d_parena, h->stage_cap) != hipSuccess) { h->d_parena = nullptr; (void)hipGetLastError(); }
         if (!h->ev_up && hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) { h->ev_up = nullptr; (void)hipGetLastError(); }
-        if (h->up != h->stream && h->ev_plan) {
+        if (h->work_queued && h->up != h->stream && h->ev_plan) {
             for (hipStream_t s : {h->stream, h->stream2}) {
                 if (!s) continue;
                 if (hipEventRecord(h->ev_plan, s) == hipSuccess) (void)hipStreamWaitEvent(h->up, h->ev_plan, 0);
@@ -113,6 +130,7 @@ struct StreamGuard {
         }
     }
     ~StreamGuard() {
+        h->arena_mode = false;                           // (a plan that failed half-way: its tables are never used)
         // everything came from the arena: nothing of the caller's is still being read, and the kernels that need the
         // tables are ordered behind ev_up on the GPU (wait_uploads) — the host does not wait for the copies
         if (!h->stage_bypass && h->stage && h->ev_up && hipEventRecord(h->ev_up, h->up) == hipSuccess) { h->up_pending = true; return; }
@@ -255,7 +273,12 @@ void nbls_destroy(nbls_handle* h) {
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
                     h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_xss, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
-    for (void* b : bufs) if (b) (void)hipFree(b);
+    {
+        std::unordered_set<const void*> in_arena;       // members that point into d_parena
+        for (const void* m : h->arena_owned) in_arena.insert(*(void* const*)m);
+        for (void* b : bufs) if (b && !in_arena.count(b)) (void)hipFree(b);
+        if (h->d_parena) (void)hipFree(h->d_parena);
+    }
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
@@ -457,6 +480,8 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     }
     HIPCHK(h, hipSetDevice(h->device));
     StreamGuard guard(h);
+    h->planned = false;
+    h->arena_mode = true;                                // alloc_copy: places in the arena, ONE upload at the end
 
     h->W.assign(winlen, winlen + nbands);
     h->inc.assign(wininc, wininc + nbands);
@@ -536,8 +561,11 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if (!same) {
             h->h_tl.clear();
             h->h_tr.clear();
-            if ((rc = alloc_copy(h, &h->d_tl, taper_left, tn))) return rc;
-            if ((rc = alloc_copy(h, &h->d_tr, taper_right, tn))) return rc;
+            h->arena_mode = false;                       // allocations of their own: they outlive the plan
+            rc = alloc_copy(h, &h->d_tl, taper_left, tn);
+            if (!rc) rc = alloc_copy(h, &h->d_tr, taper_right, tn);
+            h->arena_mode = true;
+            if (rc) return rc;
             if (tn) { h->h_tl.assign(taper_left, taper_left + tn); h->h_tr.assign(taper_right, taper_right + tn); }
         }
     }
@@ -665,6 +693,10 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         for (int i = 0; i < NS; ++i) { xss[2 * i] = xs[2 * (4 * i)]; xss[2 * i + 1] = xs[2 * (4 * i) + 1]; }
         if ((rc = alloc_copy(h, &h->d_xss, xss.data(), xss.size()))) return rc;
     }
+    // the arena's tables in one piece (copies queued before it on the same stream came from other parts of the staging arena)
+    h->arena_mode = false;
+    if (h->stage && h->d_parena && h->stage_used)
+        HIPCHK(h, hipMemcpyAsync(h->d_parena, h->stage, h->stage_used, hipMemcpyHostToDevice, h->up));
     h->planned = true;
     if (h->opt.plan_timing) {
         const auto tp3 = std::chrono::steady_clock::now();
@@ -693,6 +725,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (!h->trace_loaded) return fail(h, NBLS_ERR_STATE, "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     wait_uploads(h);
+    h->work_queued = true;
     const size_t cells = (size_t)h->nbands * h->vector_len;
     const int P = h->d_xij ? h->npairs : 1;
     // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272)
@@ -722,6 +755,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
 static int finish_pass(nbls_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->work_queued = false;
     if (h->prof && h->ev_valid) {
         float f = 0, x = 0, s = 0, t = 0;
         HIPCHK(h, hipEventElapsedTime(&f, h->ev[0], h->ev[1]));
@@ -805,6 +839,7 @@ int nbls_filter_segment(nbls_handle* h, int32_t reverse, const double* state_in,
         return fail(h, NBLS_ERR_ARG, "nbls_filter_segment: a backward segment that continues a state must be a whole number of 512-sample chunks");
     HIPCHK(h, hipSetDevice(h->device));
     wait_uploads(h);
+    h->work_queued = true;
     const size_t n = (size_t)h->nbands * h->nchans * 2 * h->nsections;
     int rc;
     if ((rc = ensure(h, &h->d_seg_state, &h->cap_seg_state, 2 * n * sizeof(double)))) return rc;

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 #include "../../include/nbls.h"
 
@@ -149,6 +150,14 @@ struct nbls_handle {
     // for it on the GPU; the next plan / geometry call waits for the upload stream before it reuses the arena
     hipEvent_t ev_up = nullptr;
     bool up_pending = false, stage_bypass = false;
+    // nbls_plan's tables live in ONE device arena at the offsets they have in the staging arena and go up in ONE copy
+    // when the plan returns (a plan is ~25 tables; each HIP call of a plan that runs beside the trace upload of a
+    // pipelined call's first group waited for the runtime's lock: 0.8 instead of 0.4 ms before the first launch)
+    bool work_queued = false;      // kernels that read the plan / geometry tables may still be queued (set by nbls_execute*, cleared by
+                                   // the calls that wait for the handle's stream): a plan has to order its uploads behind them only then
+    unsigned char* d_parena = nullptr;
+    bool arena_mode = false;
+    std::unordered_set<const void*> arena_owned;    // pointer members that point into d_parena (never freed one by one)
 
     // ---- int8 screening correlator (xcorr_screen.hip) ----
     int8_t* d_qbuf = nullptr;      // [batch][N][2][WP]
