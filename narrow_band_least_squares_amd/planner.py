@@ -203,13 +203,22 @@ def pad_sections(sos_list):
     return out
 
 
-def taper_ramps(npts, max_percentage=TAPER_FRACTION):
-    """Left and right ramps of obspy's Hann taper (ones in between are implicit)."""
+@functools.lru_cache(maxsize=8)
+def _taper_ramps_cached(npts, max_percentage):
     wlen = min(int(max_percentage * npts), int(npts / 2))
     if wlen == 0:
         return np.zeros(0), np.zeros(0)
     sides = signal.windows.hann(2 * wlen if 2 * wlen == npts else 2 * wlen + 1)
-    return np.ascontiguousarray(sides[:wlen]), np.ascontiguousarray(sides[len(sides) - wlen:])
+    tl, tr = np.ascontiguousarray(sides[:wlen]), np.ascontiguousarray(sides[len(sides) - wlen:])
+    tl.flags.writeable = False
+    tr.flags.writeable = False
+    return tl, tr
+
+
+def taper_ramps(npts, max_percentage=TAPER_FRACTION):
+    """Left and right ramps of obspy's Hann taper (ones in between are implicit).  A pure function of the trace
+    length: kept for the last few lengths (read-only arrays)."""
+    return _taper_ramps_cached(int(npts), float(max_percentage))
 
 
 def window_plan(npts, fs, window_length, window_overlap):
@@ -227,9 +236,27 @@ def pair_table(nchans):
     return np.array([(i, j) for i in range(nchans - 1) for j in range(i + 1, nchans)], dtype=np.int32)
 
 
+_co_array_cache = {}
+
+
 def co_array(rij):
-    """rij (2, N) km -> xij (P, 2) = r_i - r_j, pair table (P, 2), pinv(xij) (2, P)."""
-    rij = np.asarray(rij, dtype=np.float64)
+    """rij (2, N) km -> xij (P, 2) = r_i - r_j, pair table (P, 2), pinv(xij) (2, P).  A pure function of the
+    coordinates: the last few geometries are kept (read-only arrays)."""
+    rij = np.ascontiguousarray(rij, dtype=np.float64)
+    key = (rij.shape, rij.tobytes())
+    hit = _co_array_cache.get(key)
+    if hit is not None:
+        return hit
+    out = _co_array(rij)
+    for a in out:
+        a.flags.writeable = False
+    if len(_co_array_cache) >= 8:
+        _co_array_cache.pop(next(iter(_co_array_cache)))
+    _co_array_cache[key] = out
+    return out
+
+
+def _co_array(rij):
     idx = pair_table(rij.shape[1])
     xij = np.ascontiguousarray((rij[:, idx[:, 0]] - rij[:, idx[:, 1]]).T)
     if np.linalg.matrix_rank(xij) < LTS_DIM:
