@@ -382,57 +382,12 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     nchans, npts = _shape_of(data)
     nb = len(band_edges)
     cap = max_bands_per_pass(nchans, npts)
-    W, inc, nwin = [np.empty(nb, dtype=t) for t in (np.int32, np.int32, np.int64)]
-    plans = {}                                   # (bands usually share a few window lengths: one plan per length)
-    for b in range(nb):
-        wl = float(winlens[b])
-        if wl not in plans:
-            plans[wl] = planner.window_plan(npts, fs, winlens[b], winover)
-        W[b], inc[b], nwin[b] = plans[wl]
-    if vector_len is None:
-        vector_len = max(1, int(nwin.max()))
-    if nwin.max() > vector_len:
-        raise ValueError('could not broadcast %d windows into result rows of length %d '
-                         '(vector_len too small for this band)' % (int(nwin.max()), vector_len))
-    check_elements(nchans, alpha)
-    if cap < 1 and not prefiltered:            # not even one band's filtered trace fits the HBM budget
-        return process_segmented(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
-                                 filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
-                                 group_done)
-    cap = max(1, cap)
-    ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
-    ngroups = max(1, min(ngroups, nb))
-    # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
-    # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
-    split = os.environ.get('NBLS_PIPELINE_SPLIT')
-    if split and groups is None and ngroups > 1:
-        shares = [max(0.0, float(x)) for x in split.split(',') if x.strip()]
-        ngroups = max(1, min(len(shares), nb))
-        shares = np.cumsum(shares[:ngroups]) / max(1e-30, float(np.sum(shares[:ngroups])))
-    else:
-        # mildly decreasing shares (0.41 / 0.33 / 0.26 for three groups): what is left to do on the host after the
-        # GPU has finished is the dictionary of the LAST group (measured: 23.1 -> 22.6 ms per cfg-3 call)
-        wts = 1.0 + 0.3 * np.arange(ngroups - 1, -1, -1)
-        shares = np.cumsum(wts) / float(np.sum(wts))
-    cum = np.concatenate(([0], np.cumsum(nwin)))
-    cuts = [0]
-    for g in range(1, ngroups):
-        b = int(np.searchsorted(cum, cum[-1] * shares[g - 1]))
-        cuts.append(min(max(b, cuts[-1] + 1), nb - (ngroups - g)))
-    cuts.append(nb)
-    bounds = [(cuts[g], cuts[g + 1]) for g in range(ngroups)]
-    if max(b1 - b0 for b0, b1 in bounds) * ngroups > cap:           # HBM budget: consecutive rounds of <= cap bands
-        bounds = [(b0, min(b0 + cap, nb)) for b0 in range(0, nb, cap)]
-        sequential = True
-    else:
-        sequential = False
-
     # the trace goes up (a blocking copy from pageable memory, inside the library: the GIL is released) on a helper
     # thread while this thread designs the first group's filters AND plans its pass: the handle knows the trace's
     # shape (set_trace_shape), only nbls_execute needs the samples
     uploader = None
     upload_error = []
-    if upload and handle is None and os.environ.get('NBLS_UPLOAD_OVERLAP', '1') != '0':
+    if upload and handle is None and (cap >= 1 or prefiltered) and os.environ.get('NBLS_UPLOAD_OVERLAP', '1') != '0':
         h0 = get_handle(device, 0)
         up_rows = list(np.ascontiguousarray(data, dtype=np.float64)) if isinstance(data, np.ndarray) else data
         h0.set_trace_shape(nchans, npts, fs)
@@ -445,51 +400,102 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         uploader = threading.Thread(target=_upload, name='nbls-upload')
         uploader.start()
 
-    def upload_done():
-        nonlocal uploader
+    # (started before anything else of the call: from here on every way out joins it)
+    try:
+        W, inc, nwin = [np.empty(nb, dtype=t) for t in (np.int32, np.int32, np.int64)]
+        plans = {}                                   # (bands usually share a few window lengths: one plan per length)
+        for b in range(nb):
+            wl = float(winlens[b])
+            if wl not in plans:
+                plans[wl] = planner.window_plan(npts, fs, winlens[b], winover)
+            W[b], inc[b], nwin[b] = plans[wl]
+        if vector_len is None:
+            vector_len = max(1, int(nwin.max()))
+        if nwin.max() > vector_len:
+            raise ValueError('could not broadcast %d windows into result rows of length %d '
+                             '(vector_len too small for this band)' % (int(nwin.max()), vector_len))
+        check_elements(nchans, alpha)
+        if cap < 1 and not prefiltered:            # not even one band's filtered trace fits the HBM budget
+            return process_segmented(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type, filter_order,
+                                     filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
+                                     group_done)
+        cap = max(1, cap)
+        ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
+        ngroups = max(1, min(ngroups, nb))
+        # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
+        # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
+        split = os.environ.get('NBLS_PIPELINE_SPLIT')
+        if split and groups is None and ngroups > 1:
+            shares = [max(0.0, float(x)) for x in split.split(',') if x.strip()]
+            ngroups = max(1, min(len(shares), nb))
+            shares = np.cumsum(shares[:ngroups]) / max(1e-30, float(np.sum(shares[:ngroups])))
+        else:
+            # mildly decreasing shares (0.41 / 0.33 / 0.26 for three groups): what is left to do on the host after the
+            # GPU has finished is the dictionary of the LAST group (measured: 23.1 -> 22.6 ms per cfg-3 call)
+            wts = 1.0 + 0.3 * np.arange(ngroups - 1, -1, -1)
+            shares = np.cumsum(wts) / float(np.sum(wts))
+        cum = np.concatenate(([0], np.cumsum(nwin)))
+        cuts = [0]
+        for g in range(1, ngroups):
+            b = int(np.searchsorted(cum, cum[-1] * shares[g - 1]))
+            cuts.append(min(max(b, cuts[-1] + 1), nb - (ngroups - g)))
+        cuts.append(nb)
+        bounds = [(cuts[g], cuts[g + 1]) for g in range(ngroups)]
+        if max(b1 - b0 for b0, b1 in bounds) * ngroups > cap:           # HBM budget: consecutive rounds of <= cap bands
+            bounds = [(b0, min(b0 + cap, nb)) for b0 in range(0, nb, cap)]
+            sequential = True
+        else:
+            sequential = False
+
+        def upload_done():
+            nonlocal uploader
+            if uploader is not None:
+                uploader.join()
+                uploader = None
+                if upload_error:
+                    raise upload_error[0]
+        P = nchans * (nchans - 1) // 2
+        MB = (P + 7) // 8
+        grids = np.zeros((4, nb, vector_len))
+        mask = np.zeros((nb, vector_len, MB), dtype=np.uint8)
+        lag = np.zeros((nb, vector_len, P), dtype=np.int32) if want_lag else None
+        cmax = np.zeros((nb, vector_len, P)) if want_cmax else None
+        z = np.zeros((nb, vector_len, 2)) if want_z else None
+        res = BandBatch(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], nwin=nwin.astype(int), t=None,
+                        mask=mask, lag=lag, cmax=cmax, z=z, sos=[], W=W, inc=inc, pair_idx=None, xij=None,
+                        nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs)
+
+        deferred = []                                 # rounds collected before host_overlap has run (sequential rounds)
+
+        def collect(h, b0, b1, notify=True):
+            out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
+            grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
+            mask[b0:b1] = out['mask']
+            if want_lag or want_cmax or want_z:
+                ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
+                for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
+                    if arr is not None:
+                        arr[b0:b1] = ext[name]
+            if not notify:
+                deferred.append((b0, b1))
+            elif group_done is not None:
+                group_done(res, b0, b1)
+
+        def finish_skeleton(prep):
+            res.pair_idx, res.xij = prep.pair_idx, prep.xij
+            tt = np.zeros((nb, vector_len))
+            rows_t = {}                              # (one row of window times per distinct window plan)
+            for b in range(nb):
+                key = (int(W[b]), int(inc[b]), int(nwin[b]))
+                if key not in rows_t:
+                    rows_t[key] = window_times(t0_datenum, fs, *key)
+                tt[b, :nwin[b]] = rows_t[key]
+            res.t = tt
+
+    except BaseException:
         if uploader is not None:
             uploader.join()
-            uploader = None
-            if upload_error:
-                raise upload_error[0]
-    P = nchans * (nchans - 1) // 2
-    MB = (P + 7) // 8
-    grids = np.zeros((4, nb, vector_len))
-    mask = np.zeros((nb, vector_len, MB), dtype=np.uint8)
-    lag = np.zeros((nb, vector_len, P), dtype=np.int32) if want_lag else None
-    cmax = np.zeros((nb, vector_len, P)) if want_cmax else None
-    z = np.zeros((nb, vector_len, 2)) if want_z else None
-    res = BandBatch(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], nwin=nwin.astype(int), t=None,
-                    mask=mask, lag=lag, cmax=cmax, z=z, sos=[], W=W, inc=inc, pair_idx=None, xij=None,
-                    nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs)
-
-    deferred = []                                 # rounds collected before host_overlap has run (sequential rounds)
-
-    def collect(h, b0, b1, notify=True):
-        out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
-        grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
-        mask[b0:b1] = out['mask']
-        if want_lag or want_cmax or want_z:
-            ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
-            for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
-                if arr is not None:
-                    arr[b0:b1] = ext[name]
-        if not notify:
-            deferred.append((b0, b1))
-        elif group_done is not None:
-            group_done(res, b0, b1)
-
-    def finish_skeleton(prep):
-        res.pair_idx, res.xij = prep.pair_idx, prep.xij
-        tt = np.zeros((nb, vector_len))
-        rows_t = {}                              # (one row of window times per distinct window plan)
-        for b in range(nb):
-            key = (int(W[b]), int(inc[b]), int(nwin[b]))
-            if key not in rows_t:
-                rows_t[key] = window_times(t0_datenum, fs, *key)
-            tt[b, :nwin[b]] = rows_t[key]
-        res.t = tt
-
+        raise
     launched = []
     prep = None
     try:
