@@ -514,6 +514,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         if (W > maxW) maxW = W;
     }
     h->unit_off[nbands] = (int32_t)U;
+    h->woff = woff;
     if (U > 0x7fffffffLL / (P > 0 ? P : 1)) return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: too many (unit, pair) items for one launch");
     h->nunits = U;
     h->maxW = maxW;
@@ -728,12 +729,12 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     h->work_queued = true;
     const size_t cells = (size_t)h->nbands * h->vector_len;
     const int P = h->d_xij ? h->npairs : 1;
-    // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272)
+    // padding beyond nwin[b] is zeros (narrow_band_least_squares.py:268-272): the result block (grids + weight mask) is
+    // cleared here; the per-pair side arrays (lag, cmax, weights, z: 25 MB at cfg-3, five fill kernels per band group) are
+    // written for every computed window and read for no other — the rows nobody computed are zeroed on the host by the
+    // rare caller that fetches them (nbls_fetch: zero_uncomputed)
+    (void)cells; (void)P;
     HIPCHK(h, hipMemsetAsync(h->d_res, 0, h->res_bytes, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_z, 0, 2 * cells * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_lag, 0, cells * P * sizeof(int32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_cmax, 0, cells * P * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_wts, 0, cells * P, h->stream));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -798,10 +799,20 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
             if (hg[g]) HIPCHK(h, copy_sync(h, hg[g], dg[g], cells * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (nwin) memcpy(nwin, h->nwin.data(), h->nbands * sizeof(int32_t));
-    if (lag) HIPCHK(h, copy_sync(h, lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (cmax) HIPCHK(h, copy_sync(h, cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost));
-    if (weights) HIPCHK(h, copy_sync(h, weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost));
-    if (z) HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost));
+    // rows of windows this plan did not compute (beyond a band's count, outside a window slice) are zeros
+    auto zero_uncomputed = [&](void* out, size_t row_bytes) {
+        unsigned char* o = (unsigned char*)out;
+        for (int b = 0; b < h->nbands; ++b) {
+            const int64_t first = (int)h->woff.size() == h->nbands ? h->woff[b] : 0, n = h->nwin[b];
+            unsigned char* band = o + (size_t)b * h->vector_len * row_bytes;
+            if (first > 0) memset(band, 0, (size_t)first * row_bytes);
+            if (first + n < h->vector_len) memset(band + (size_t)(first + n) * row_bytes, 0, (size_t)(h->vector_len - first - n) * row_bytes);
+        }
+    };
+    if (lag) { HIPCHK(h, copy_sync(h, lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost)); zero_uncomputed(lag, h->npairs * sizeof(int32_t)); }
+    if (cmax) { HIPCHK(h, copy_sync(h, cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(cmax, h->npairs * sizeof(double)); }
+    if (weights) { HIPCHK(h, copy_sync(h, weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost)); zero_uncomputed(weights, (size_t)h->npairs); }
+    if (z) { HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(z, 2 * sizeof(double)); }
     return NBLS_OK;
 }
 
