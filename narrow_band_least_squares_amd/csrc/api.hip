@@ -653,8 +653,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     }
     if (xcorr_impl == 3) {
         const int WP_ = h->screen_wp;
-        // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache
-        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 96;
+        // unit batches small enough for the quantised windows to stay in the 256 MiB Infinity Cache (192 MB: measured
+        // against 96 — the value of rounds 1-2 — and 384 at every BASELINE shape: 0.2-1.2 % of the pass, fewer launch tails)
+        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 192;
         int64_t batch = (int64_t)(batch_mb << 20) / ((int64_t)h->nchans * 2 * WP_);
         if (batch < 64) batch = 64;
         if (batch > U) batch = U > 0 ? U : 1;

@@ -1522,7 +1522,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     int64_t batch = h->screen_batch;
     {
         const int64_t U = ue - ub;
-        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 96;
+        const int64_t batch_mb = h->opt.screen_batch_mb > 0 ? h->opt.screen_batch_mb : 192;
         int64_t bw = (int64_t)(batch_mb << 20) / ((int64_t)N * 2 * a.WP);
         if (bw < 64) bw = 64;
         if (bw < batch) batch = bw;                  // (never more than the buffers were sized for)
