@@ -554,7 +554,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if (nsections == 0 && nbands != 1)
         return fail(h, NBLS_ERR_ARG, "nbls_plan: an unfiltered plan has exactly one band");
     if ((rc = alloc_copy(h, &h->d_M, M.data(), M.size()))) return rc;
-    {   // the ramps (5 % of the trace each: 0.7 MB at cfg-3, most of a plan's upload) only when they differ from what is there
+    {   // the ramps (1 % of the trace each: 0.14 MB at cfg-3, a quarter of a plan's upload) only when they differ from what is there
         const size_t tn = (size_t)taper_len;
         const bool same = h->d_tl && h->d_tr && h->h_tl.size() == tn && h->h_tr.size() == tn &&
                           (tn == 0 || (memcmp(h->h_tl.data(), taper_left, tn * sizeof(double)) == 0 &&

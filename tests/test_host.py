@@ -730,3 +730,33 @@ def test_filter_responses_are_scipys_bit_for_bit():
     assert planner.sosfreqz_bands([np.zeros((2, 6))], 512, 40.0) is None               # integer worN: SciPy's FFT branch
     assert planner.sosfreqz_bands([np.zeros((0, 6))], fr, 40.0) is None
     assert planner.sosfreqz_bands([np.zeros((2, 6), dtype=np.float32)], fr, 40.0) is None
+
+
+def test_plan_constants_are_kept_read_only_and_equal_a_fresh_computation():
+    """planner keeps the constants that depend on (pair count, alpha), the trace length or the geometry between calls
+    (LCG subsets, factor tables, taper ramps, co-array).  What comes back must be what a fresh computation gives, must
+    not be writable (it is shared between calls), and a different argument must not hit a stale entry."""
+    from narrow_band_least_squares_amd import planner, synthetic
+    rij = synthetic.array_geometry(8, 1.0, seed=3)
+    a = planner.co_array(rij)
+    b = planner.co_array(rij.copy())
+    assert all(x is y for x, y in zip(a, b)) and not any(x.flags.writeable for x in a)
+    fresh = planner._co_array(np.ascontiguousarray(rij, dtype=np.float64))
+    for x, y in zip(a, fresh):
+        np.testing.assert_array_equal(x, y)
+    other = planner.co_array(rij * 1.5)
+    assert not np.array_equal(other[0], a[0])
+    for k in range(12):                                   # more geometries than the cache keeps: the first one is recomputed, equal
+        planner.co_array(rij + k)
+    np.testing.assert_array_equal(planner.co_array(rij)[2], fresh[2])
+    tl, tr = planner.taper_ramps(4000)
+    tl2, tr2 = planner.taper_ramps(4000)
+    assert tl is tl2 and not tl.flags.writeable and len(tl) == int(planner.TAPER_FRACTION * 4000)
+    assert len(planner.taper_ramps(4400)[0]) == int(planner.TAPER_FRACTION * 4400)
+    p1 = planner.lts_plan(a[0], 0.5)
+    p2 = planner.lts_plan(a[0], 0.5)
+    np.testing.assert_array_equal(p1['rew_table'], p2['rew_table'])
+    assert p1['rew_table'] is not p2['rew_table'] and p1['raw_factor'] == p2['raw_factor']
+    p1['rew_table'][0] = 123.0                            # the caller's copy is its own
+    assert planner.lts_plan(a[0], 0.5)['rew_table'][0] == 1.0
+    assert planner.lts_plan(a[0], 0.75)['h'] != p1['h']
