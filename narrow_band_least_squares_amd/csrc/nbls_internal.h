@@ -29,7 +29,7 @@ struct nbls_options {
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
     int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
-    int screen_batch_mb = 96;  // quantised-window bytes per unit batch
+    int screen_batch_mb = 192;  // quantised-window bytes per unit batch
     int overlap = 0;           // 1: solve of batch k on a second stream while batch k+1 is correlated
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
     int filter_nomfma = 0;     // 1: VALU state kernel
