@@ -132,10 +132,15 @@ def main():
     ap.add_argument('--independent-calls', choices=['auto', 'on', 'off'], default='auto',
                     help='after the main measurement, time one whole single-GPU call per rank on the rank\'s own trace '
                          '(no collective; extra field `independent_calls`).  auto: in band-sharded runs under a launcher')
+    ap.add_argument('--transport-lib', default=None,
+                    help='REHEARSAL ONLY (one-GPU box): a library with RCCL\'s ten entry points to use instead of RCCL, several '
+                         'ranks on one device (tests/c_caller/loopback_rccl.cpp); the numbers of such a run mean nothing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-noise', action='store_true')
     args = ap.parse_args()
 
+    if args.transport_lib:
+        dist.set_transport_library(args.transport_lib, allow_shared_device=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))       # PROCESSES of this job (a launcher's ranks); 1 without a launcher
     rank = int(os.environ.get('RANK', '0'))
     # Two ways to use N GPUs (dist.py): one process per GPU under a launcher (WORLD_SIZE = N), or — no launcher —

@@ -205,6 +205,28 @@ int nbls_device_results(nbls_handle* h, void** ptrs, int64_t* bytes_per_grid);
 int nbls_result_layout(nbls_handle* h, int64_t* out4);
 int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes);
 
+/* ---- streamed results: the rows of a pass reach the host batch by batch, while the pass is still running --------
+ * Replaces "wait for the whole pass, then build the result rows and the dropped-element dictionary"
+ * (narrow_band_least_squares.py:104-124 runs once per band, as each band's ltsva() returns; here a pass covers all
+ * bands, and its units are processed in batches of consecutive (band, window) units):
+ *   nbls_stream_results(h, 1)     the NEXT nbls_execute* run every unit batch as a complete chain
+ *                                 (correlation -> solve -> weight mask) and queue, behind it, a copy of that batch's
+ *                                 rows of the result block into a PINNED host mirror of the block owned by the
+ *                                 library (same layout as nbls_result_layout / nbls_fetch_packed)
+ *   nbls_result_batches(h, &n)    after nbls_execute*: how many batches the pass was cut into (>= 1)
+ *   nbls_wait_result_batch(h, k, out4, &block)
+ *                                 wait until batch k has landed; out4 = {u0, u1, c0, c1}: the batch holds the units
+ *                                 [u0, u1) of the plan (band-major order: all windows of band 0, then band 1, ...) and
+ *                                 its rows are the cells [c0, c1) of each grid / of the mask (cell = band * vector_len
+ *                                 + window); *block = the mirror.  Batches finish in index order.  Cells outside
+ *                                 the batches waited for so far are undefined; the mirror is valid until the handle's
+ *                                 next nbls_execute*.  The host may work on batch k (build its dictionary entries)
+ *                                 while the GPU runs batch k+1.
+ * Results are identical to the unstreamed pass; nbls_fetch* still work afterwards. */
+int nbls_stream_results(nbls_handle* h, int32_t on);
+int nbls_result_batches(nbls_handle* h, int32_t* nbatches);
+int nbls_wait_result_batch(nbls_handle* h, int32_t k, int64_t* out4, const void** host_block);
+
 /* ---- multi-GPU: ONE grouped RCCL operation collects every GPU's result block ----------------------
  * Replaces the joblib fan-out / collection of narrow_band_least_squares_parallel()
  * (narrow_band_least_squares.py:285 and :291-320).  Bands (or window slices) are sharded by the host;
@@ -229,9 +251,12 @@ int nbls_fetch_packed(nbls_handle* h, void* out, int64_t nbytes);
  *       copy to the host has finished.
  *   nbls_comm_destroy(h)            release the communicator (also done by nbls_destroy)
  * RCCL is resolved with dlopen at the first of these calls (librccl.so.1, librccl.so, /opt/rocm/lib/...).
- * Environment, for rehearsals on a one-GPU box only: NBLS_RCCL_LIB names a library with the same ten entry
- * points to try first (tests/c_caller/loopback_rccl.cpp), NBLS_ALLOW_SHARED_DEVICE=1 lets nbls_comm_init_all
- * take several handles of one device.                                                              */
+ *   nbls_comm_set_library(path, allow_shared_device)
+ *       for rehearsals on a one-GPU box: resolve the ten entry points from `path` instead (the tests' loopback
+ *       stand-in, tests/c_caller/loopback_rccl.cpp); allow_shared_device = 1 lets nbls_comm_init_all take several
+ *       handles of one device.  Must come before the first comm call (NBLS_ERR_STATE once RCCL has been resolved
+ *       from elsewhere); path NULL = RCCL.  The library reads no environment variable.              */
+int nbls_comm_set_library(const char* path, int32_t allow_shared_device);
 int nbls_comm_init_all(nbls_handle* const* hs, int32_t n);
 int nbls_comm_unique_id(void* id, int32_t nbytes);
 int nbls_comm_init_rank(nbls_handle* h, const void* id, int32_t world, int32_t rank);
@@ -248,8 +273,9 @@ int nbls_comm_destroy(nbls_handle* h);
 /* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects
  * between implementations that give IDENTICAL results (A/B timing; tests that check kernels against each other):
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
- *   "lts_generic_h", "lts_coop_threads", "verify_global", "verify_block", "screen_b_dma", "screen_kold", "screen_tb4", "quantize_slab", "screen_nsl1", "screen_batch_mb",
- *   "overlap", "filter_nofuse", "filter_nomfma", "filter_store_y1";
+ *   "lts_generic_h", "lts_coop_threads", "screen_tb4", "screen_nsl1", "screen_static", "screen_batch_mb",
+ *   "overlap" (the solve of a unit batch on a second stream beside the next batch's correlation), "filter_nofuse",
+ *   "filter_nomfma";
  *   "stream_priority" (applied at once; the handle must be idle): 0 normal, > 0 lower, < 0 higher, clamped to the
  *   device's range — for several handles of one GPU whose passes run side by side.
  * A developer build (make dev, -DNBLS_DEVELOPER; nbls_developer_build() == 1) adds "ablate" (skips kernel parts,
@@ -278,8 +304,9 @@ int nbls_probe_mfma_f64(nbls_handle* h, const double* a, const double* b, double
  * out[lane*4 + reg] int32. */
 int nbls_probe_mfma_i8(nbls_handle* h, const int32_t* a, const int32_t* b, int32_t* out);
 
-/* Developer statistic of the int8 screening correlator (last unit batch): out4 = {ordered pairs,
- * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair}. */
+/* Developer statistic of the int8 screening correlator (last unit batch): out8 (EIGHT int64) = {ordered pairs,
+ * pairs whose candidate buffer overflowed, total candidates, max candidates per ordered pair, runs of consecutive
+ * listed lags, listed lags that sit in a run of two or more, 0, 0}. */
 int nbls_debug_screen_stats(nbls_handle* h, int64_t* out8);
 /* Developer: mean s_memtime cycle counts of the phases of the wave-per-unit FAST-LTS kernel
 (developer build, options "screen_stamps" / "lts_stamps"): out8 = {setup+medians, elemental starts,

@@ -20,7 +20,8 @@ EXPORTS = [
     'nbls_set_trace_rows', 'nbls_result_layout', 'nbls_fetch_packed', 'nbls_comm_init_all', 'nbls_comm_unique_id',
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
     'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown', 'nbls_filter_segment',
-    'nbls_set_filtered', 'nbls_load_result_block',
+    'nbls_set_filtered', 'nbls_load_result_block', 'nbls_stream_results', 'nbls_result_batches', 'nbls_wait_result_batch',
+    'nbls_comm_set_library',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -83,6 +84,10 @@ def load_library(path=None):
     lib.nbls_load_result_block.argtypes = [vp, C.c_void_p, C.c_int64]
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
+    lib.nbls_comm_set_library.argtypes = [C.c_char_p, C.c_int32]
+    lib.nbls_stream_results.argtypes = [vp, C.c_int32]
+    lib.nbls_result_batches.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.nbls_wait_result_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
     lib.nbls_set_trace_from.argtypes = [vp, vp]
     lib.nbls_filter_segment.argtypes = [vp, C.c_int32, dp, dp]
     lib.nbls_set_filtered.argtypes = [vp, C.c_int32, dp]
@@ -333,6 +338,31 @@ class Handle:
         grids = buf[:4 * cells].reshape(4, B, VL)
         mask = buf.view(np.uint8)[moff:moff + cells * mb].reshape(B, VL, mb)
         return dict(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], mask=mask)
+
+    def stream_results(self, on=True):
+        """The next passes deliver their rows batch by batch into a pinned host mirror of the result block
+        (``nbls_stream_results``); see ``result_batches`` / ``wait_result_batch``."""
+        self._chk(self.lib.nbls_stream_results(self._h, int(bool(on))))
+
+    def result_batches(self):
+        n = C.c_int32()
+        self._chk(self.lib.nbls_result_batches(self._h, C.byref(n)))
+        return n.value
+
+    def wait_result_batch(self, k):
+        """Wait for batch ``k`` of the queued pass -> (u0, u1, c0, c1, grids (4, B*VL) float64, mask (B*VL, MB) uint8):
+        the batch's units [u0, u1) own the cells [c0, c1) of the two VIEWS of the library's pinned mirror (valid until
+        the handle's next pass; cells of batches not yet waited for are undefined)."""
+        out = (C.c_int64 * 4)()
+        blk = C.c_void_p()
+        self._chk(self.lib.nbls_wait_result_batch(self._h, int(k), out, C.byref(blk)))
+        cells = self.nbands * self.vector_len
+        mb = (self.npairs + 7) // 8
+        raw = (C.c_uint8 * (cells * (32 + mb))).from_address(blk.value)
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        grids = buf[:32 * cells].view(np.float64).reshape(4, cells)
+        mask = buf[32 * cells:].reshape(cells, mb)
+        return out[0], out[1], out[2], out[3], grids, mask
 
     def fetch_filtered(self, band):
         out = np.empty((self.nchans, self.npts))

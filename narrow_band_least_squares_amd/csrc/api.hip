@@ -282,6 +282,9 @@ void nbls_destroy(nbls_handle* h) {
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->bev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->rev) (void)hipEventDestroy(e);
+    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->h_res) (void)hipHostFree(h->h_res);
     if (h->ev_xd) (void)hipEventDestroy(h->ev_xd);
     if (h->ev_plan) (void)hipEventDestroy(h->ev_plan);
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);
@@ -478,9 +481,35 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         for (int i = 0; i < lts->nstarts * 4; ++i)
             if (lts->starts[i] >= P) return fail(h, NBLS_ERR_ARG, "nbls_plan: start index out of range");
     }
+    // The filter tables first: pure host arithmetic.  Every HIP call of the plan comes AFTER them — while the trace of a
+    // pipelined call is still going up on another thread (nbls_upload_rows) each HIP call waits for the runtime's lock
+    // behind a row copy (~0.15 ms apiece), and the first launch of the call waits for this plan.
+    const auto tp0 = std::chrono::steady_clock::now();
+    const int D = 2 * nsections;
+    const int GG = NBLS_FILTER_GROUP;
+    std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
+    {
+        // long-double table arithmetic, 30-100 us per band: the bands are dealt to a few host threads (the
+        // plan sits on the critical path of a call: the GPU has nothing to do until it is through)
+        double* const fwp = FW.data();
+        double* const mp = M.data();
+        const int nt = nsections > 0 ? (nbands >= 32 ? 8 : (nbands >= 12 ? 4 : (nbands >= 6 ? 2 : 1))) : 0;
+        auto work = [&](int t) {
+            for (int b = t; b < nbands; b += nt)
+                filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
+                              fwp + (size_t)b * NBLS_FILTER_CHUNK * D, mp + (size_t)b * (GG + 1) * D * D);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        if (nt > 0) work(0);
+        for (auto& x : th) x.join();
+    }
+    const auto tp1 = std::chrono::steady_clock::now();
+
     HIPCHK(h, hipSetDevice(h->device));
     StreamGuard guard(h);
     h->planned = false;
+    h->res_loaded = false;
     h->arena_mode = true;                                // alloc_copy: places in the arena, ONE upload at the end
 
     h->W.assign(winlen, winlen + nbands);
@@ -528,27 +557,6 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     h->nchunks = (h->npts + NBLS_FILTER_CHUNK - 1) / NBLS_FILTER_CHUNK;
 
     int rc;
-    const auto tp0 = std::chrono::steady_clock::now();
-    const int D = 2 * nsections;
-    const int GG = NBLS_FILTER_GROUP;
-    std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
-    {
-        // long-double table arithmetic, 30-100 us per band: the bands are dealt to a few host threads (the first
-        // group's plan sits on the critical path of a pipelined call: the GPU has nothing to do until it is through)
-        double* const fwp = FW.data();
-        double* const mp = M.data();
-        const int nt = nsections > 0 ? (nbands >= 12 ? 4 : (nbands >= 6 ? 2 : 1)) : 0;
-        auto work = [&](int t) {
-            for (int b = t; b < nbands; b += nt)
-                filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
-                              fwp + (size_t)b * NBLS_FILTER_CHUNK * D, mp + (size_t)b * (GG + 1) * D * D);
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        if (nt > 0) work(0);
-        for (auto& x : th) x.join();
-    }
-    const auto tp1 = std::chrono::steady_clock::now();
     if ((rc = alloc_copy(h, &h->d_fw, FW.data(), FW.size()))) return rc;
     if ((rc = alloc_copy(h, &h->d_sos, sos, (size_t)nbands * nsections * 6))) return rc;
     if (nsections == 0 && nbands != 1)
@@ -740,7 +748,23 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     h->solve_done = false;
-    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && h->opt.overlap;
+    h->last_stage_mask = stage_mask;
+    // per-batch solves: behind each unit batch of the correlation stage (streamed results: a batch's rows are complete
+    // while later batches are still being correlated), on the second stream with option "overlap"
+    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && (h->opt.overlap || h->stream_results);
+    h->solve_on_stream2 = h->fuse_solve && h->opt.overlap && h->stream2;
+    // (a caller that did not wait for every batch of the previous pass: its copies read the block this pass clears)
+    if (!h->rbatches.empty() && h->cstream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->rev[2 * (h->rbatches.size() - 1) + 1], 0));
+    h->rbatches.clear();
+    if (h->stream_results) {
+        if (!h->cstream) HIPCHK(h, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+        if (h->cap_hres < h->res_bytes) {
+            HIPCHK(h, hipStreamSynchronize(h->cstream));
+            if (h->h_res) { (void)hipHostFree(h->h_res); h->h_res = nullptr; h->cap_hres = 0; }
+            HIPCHK(h, hipHostMalloc((void**)&h->h_res, h->res_bytes ? h->res_bytes : 8, hipHostMallocDefault));
+            h->cap_hres = h->res_bytes ? h->res_bytes : 8;
+        }
+    }
     // nbls_execute_after: this pass's filter may run beside the other handle's correlation stage (memory-bound next to
     // matrix-core-bound), its own correlation stage starts when the other one's is through
     if (h->after && (stage_mask & 2)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->after->ev_xd, 0));
@@ -750,6 +774,75 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if ((stage_mask & 4) && !h->solve_done) HIPCHK(h, nbls_launch_solve(h));
     if (h->prof) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_valid = true; }
+    // streamed results of a pass that was not cut into batches (general correlators, stage subsets, no units): ONE batch
+    if (h->stream_results && h->rbatches.empty()) HIPCHK(h, nbls_queue_result_batch(h, 0, h->nunits, h->stream));
+    return NBLS_OK;
+}
+
+}  // extern "C"
+
+// The rows of units [u0, u1) are complete once `producer` has run what is queued on it: their part of the result block
+// (the cell range [c0, c1) of each of the four grids and of the mask; padding cells between two bands ride along, they
+// are zero) goes to the pinned mirror on the copy stream, and an event marks the landing (nbls_wait_result_batch).
+hipError_t nbls_queue_result_batch(nbls_handle* h, int64_t u0, int64_t u1, hipStream_t producer) {
+    if (!h->stream_results || !h->cstream || !h->h_res) return hipSuccess;
+    const size_t k = h->rbatches.size();
+    while (h->rev.size() < 2 * (k + 1)) {
+        hipEvent_t e;
+        hipError_t ce = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (ce != hipSuccess) return ce;
+        h->rev.push_back(e);
+    }
+    nbls_handle::result_batch rb{u0, u1, 0, 0};
+    if (u1 > u0) {
+        auto cell = [&](int64_t u) {
+            const int b = (int)(std::upper_bound(h->unit_off.begin(), h->unit_off.end(), (int32_t)u) - h->unit_off.begin()) - 1;
+            const int64_t first = (int)h->woff.size() == h->nbands ? h->woff[b] : 0;
+            return (int64_t)b * h->vector_len + first + (u - h->unit_off[b]);
+        };
+        rb.c0 = cell(u0);
+        rb.c1 = cell(u1 - 1) + 1;
+    }
+    hipError_t e = hipEventRecord(h->rev[2 * k], producer);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(h->cstream, h->rev[2 * k], 0)) != hipSuccess) return e;
+    if (rb.c1 > rb.c0) {
+        const size_t cells = (size_t)h->nbands * h->vector_len;
+        for (int g = 0; g < 4; ++g) {
+            const size_t off = ((size_t)g * cells + (size_t)rb.c0) * sizeof(double);
+            if ((e = hipMemcpyAsync(h->h_res + off, h->d_res + off, (size_t)(rb.c1 - rb.c0) * sizeof(double), hipMemcpyDeviceToHost, h->cstream)) != hipSuccess) return e;
+        }
+        const size_t moff = 4 * cells * sizeof(double) + (size_t)rb.c0 * h->mask_bytes;
+        if ((e = hipMemcpyAsync(h->h_res + moff, h->d_res + moff, (size_t)(rb.c1 - rb.c0) * h->mask_bytes, hipMemcpyDeviceToHost, h->cstream)) != hipSuccess) return e;
+    }
+    if ((e = hipEventRecord(h->rev[2 * k + 1], h->cstream)) != hipSuccess) return e;
+    h->rbatches.push_back(rb);
+    return hipSuccess;
+}
+
+extern "C" {
+
+int nbls_stream_results(nbls_handle* h, int32_t on) {
+    if (!h) return NBLS_ERR_ARG;
+    h->stream_results = on != 0;
+    return NBLS_OK;
+}
+
+int nbls_result_batches(nbls_handle* h, int32_t* nbatches) {
+    if (!h || !nbatches) return NBLS_ERR_ARG;
+    *nbatches = h->stream_results ? (int32_t)h->rbatches.size() : 0;
+    return NBLS_OK;
+}
+
+int nbls_wait_result_batch(nbls_handle* h, int32_t k, int64_t* out4, const void** host_block) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!h->stream_results || k < 0 || (size_t)k >= h->rbatches.size())
+        return fail(h, NBLS_ERR_STATE, "nbls_wait_result_batch: no such batch (nbls_stream_results + nbls_execute first)");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->rev[2 * (size_t)k + 1]));
+    const nbls_handle::result_batch& rb = h->rbatches[(size_t)k];
+    if (out4) { out4[0] = rb.u0; out4[1] = rb.u1; out4[2] = rb.c0; out4[3] = rb.c1; }
+    if (host_block) *host_block = h->h_res;
     return NBLS_OK;
 }
 
@@ -757,6 +850,7 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
 static int finish_pass(nbls_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->cstream && !h->rbatches.empty()) HIPCHK(h, hipStreamSynchronize(h->cstream));
     h->work_queued = false;
     if (h->prof && h->ev_valid) {
         float f = 0, x = 0, s = 0, t = 0;
@@ -766,12 +860,20 @@ static int finish_pass(nbls_handle* h) {
         HIPCHK(h, hipEventElapsedTime(&t, h->ev[0], h->ev[3]));
         h->tim.filter_ms = f; h->tim.xcorr_ms = x; h->tim.solve_ms = s; h->tim.total_ms = t;
         h->tim.quantize_ms = h->tim.screen_ms = h->tim.verify_ms = 0.0;
-        for (int b = 0; b + 3 < h->bev_used; b += 4) {
-            float q = 0, sc = 0, v = 0;
+        double fused_solve = 0.0;
+        for (int b = 0; b + 4 < h->bev_used; b += 5) {
+            float q = 0, sc = 0, v = 0, so = 0;
             HIPCHK(h, hipEventElapsedTime(&q, h->bev[b], h->bev[b + 1]));
             HIPCHK(h, hipEventElapsedTime(&sc, h->bev[b + 1], h->bev[b + 2]));
             HIPCHK(h, hipEventElapsedTime(&v, h->bev[b + 2], h->bev[b + 3]));
-            h->tim.quantize_ms += q; h->tim.screen_ms += sc; h->tim.verify_ms += v;
+            if (h->prof_fused) HIPCHK(h, hipEventElapsedTime(&so, h->bev[b + 3], h->bev[b + 4]));
+            h->tim.quantize_ms += q; h->tim.screen_ms += sc; h->tim.verify_ms += v; fused_solve += so;
+        }
+        if (h->prof_fused && h->bev_used > 0) {
+            // per-batch solves sit inside the correlation stage's interval: report the stages as if they were separate
+            // (with option "overlap" the solves run beside the next batch's correlation: their sum is not wall time)
+            h->tim.solve_ms += fused_solve;
+            if (!h->solve_on_stream2) h->tim.xcorr_ms -= fused_solve;
         }
         h->bev_used = 0;
         h->tim.xcorr_impl = h->xcorr_impl_used;
@@ -810,10 +912,25 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
             if (first + n < h->vector_len) memset(band + (size_t)(first + n) * row_bytes, 0, (size_t)(h->vector_len - first - n) * row_bytes);
         }
     };
-    if (lag) { HIPCHK(h, copy_sync(h, lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost)); zero_uncomputed(lag, h->npairs * sizeof(int32_t)); }
-    if (cmax) { HIPCHK(h, copy_sync(h, cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(cmax, h->npairs * sizeof(double)); }
-    if (weights) { HIPCHK(h, copy_sync(h, weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost)); zero_uncomputed(weights, (size_t)h->npairs); }
-    if (z) { HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(z, 2 * sizeof(double)); }
+    // the side arrays are not cleared by a pass (see nbls_execute_stages): what a stage that did NOT run in the last pass
+    // would have written is zeros here, not the previous pass's values
+    const bool ran_x = (h->last_stage_mask & 2) != 0, ran_s = (h->last_stage_mask & 4) != 0;
+    if (lag) {
+        if (ran_x) { HIPCHK(h, copy_sync(h, lag, h->d_lag, cells * h->npairs * sizeof(int32_t), hipMemcpyDeviceToHost)); zero_uncomputed(lag, h->npairs * sizeof(int32_t)); }
+        else memset(lag, 0, cells * h->npairs * sizeof(int32_t));
+    }
+    if (cmax) {
+        if (ran_x) { HIPCHK(h, copy_sync(h, cmax, h->d_cmax, cells * h->npairs * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(cmax, h->npairs * sizeof(double)); }
+        else memset(cmax, 0, cells * h->npairs * sizeof(double));
+    }
+    if (weights) {
+        if (ran_s) { HIPCHK(h, copy_sync(h, weights, h->d_wts, cells * h->npairs, hipMemcpyDeviceToHost)); zero_uncomputed(weights, (size_t)h->npairs); }
+        else memset(weights, 0, cells * h->npairs);
+    }
+    if (z) {
+        if (ran_s) { HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(z, 2 * sizeof(double)); }
+        else memset(z, 0, 2 * cells * sizeof(double));
+    }
     return NBLS_OK;
 }
 
@@ -909,6 +1026,7 @@ int nbls_load_result_block(nbls_handle* h, const void* block, int64_t nbytes) {
     h->d_vel = h->d_baz = h->d_mdccm = h->d_sig = nullptr;   // the views of the last plan no longer describe the block
     h->d_mask = nullptr;
     h->planned = false;                                      // ... and a new pass needs a new plan
+    h->res_loaded = true;                                    // (nbls_comm_gather: this block is a result, whatever its allocation's size)
     return NBLS_OK;
 }
 

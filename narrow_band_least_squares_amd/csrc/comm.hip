@@ -43,6 +43,8 @@ struct RcclApi {
 
 std::mutex g_mu;
 RcclApi g_api;
+std::string g_lib_path;          // nbls_comm_set_library: a library to resolve the ten entry points from instead of librccl
+bool g_allow_shared = false;     // ... and whether nbls_comm_init_all may take several handles of one device
 
 int cfail(nbls_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -53,14 +55,17 @@ int cfail(nbls_handle* h, int code, const std::string& msg) {
 RcclApi* rccl(std::string* why) {
     std::lock_guard<std::mutex> l(g_mu);
     if (g_api.lib) return &g_api;
-    // NBLS_RCCL_LIB: another library with the same ten entry points, tried first (the tests use a loopback stand-in
-    // to run several ranks of ONE process on one GPU: tests/c_caller/loopback_rccl.cpp)
-    const char* names[] = {getenv("NBLS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // nbls_comm_set_library: ONLY that library (the tests' loopback stand-in runs several ranks of one process on
+    // one GPU: tests/c_caller/loopback_rccl.cpp); otherwise RCCL by its usual names.  No environment variable is read.
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* lib = nullptr;
-    for (const char* n : names)
-        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!g_lib_path.empty()) lib = dlopen(g_lib_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    else
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!lib) {
-        if (why) *why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "");
+        const char* de = dlerror();
+        if (why) *why = std::string("RCCL not found (dlopen ") + (g_lib_path.empty() ? "librccl.so.1" : g_lib_path.c_str()) + "): " + (de ? de : "");
         return nullptr;
     }
 #define NBLS_SYM(field, name)                                              \
@@ -99,6 +104,15 @@ RcclApi* rccl(std::string* why) {
 }  // namespace
 
 extern "C" {
+
+int nbls_comm_set_library(const char* path, int32_t allow_shared_device) {
+    std::lock_guard<std::mutex> l(g_mu);
+    const std::string want = path ? path : "";
+    if (g_api.lib && want != g_lib_path) return NBLS_ERR_STATE;      // already resolved from somewhere else
+    g_lib_path = want;
+    g_allow_shared = allow_shared_device != 0;
+    return NBLS_OK;
+}
 
 int nbls_comm_unique_id(void* id, int32_t nbytes) {
     if (!id || nbytes < (int32_t)sizeof(ncclUniqueId)) return NBLS_ERR_ARG;
@@ -153,10 +167,9 @@ int nbls_comm_init_all(nbls_handle* const* hs, int32_t n) {
     for (int i = 0; i < n; ++i) {
         (void)nbls_comm_destroy(hs[i]);
         devs[i] = hs[i]->device;
-        // (RCCL itself refuses a device twice; NBLS_ALLOW_SHARED_DEVICE=1 is for the loopback stand-in of the tests)
-        const char* shared = getenv("NBLS_ALLOW_SHARED_DEVICE");
+        // (RCCL itself refuses a device twice; nbls_comm_set_library(path, 1) is for the loopback stand-in of the tests)
         for (int j = 0; j < i; ++j)
-            if (devs[j] == devs[i] && !(shared && shared[0] == '1'))
+            if (devs[j] == devs[i] && !g_allow_shared)
                 return cfail(hs[0], NBLS_ERR_ARG, "nbls_comm_init_all: two handles on the same device");
     }
     std::vector<ncclComm_t> comms(n, nullptr);
@@ -217,9 +230,22 @@ int nbls_comm_gather(nbls_handle* const* hs, int32_t n, int32_t root, int64_t bl
         nbls_handle* h = hs[i];
         bool ok = hipnote(h, hipSetDevice(h->device), "hipSetDevice");
         bool use_own = ok;
-        if (ok && h->planned && (int64_t)h->res_bytes + 8 > block_bytes) {
+        if (ok && (h->planned || h->res_loaded) && (int64_t)h->res_bytes + 8 > block_bytes) {
             note(h, NBLS_ERR_ARG, "nbls_comm_gather: block_bytes smaller than the result block + status word");
             use_own = false;
+        }
+        if (ok && use_own && h->res_loaded && h->d_res && h->cap_res < (size_t)block_bytes) {
+            // a block assembled on the host (nbls_load_result_block) without nbls_reserve_results(block_bytes): it is
+            // this rank's RESULT, not a failed rank's leftovers — move it into an allocation of the gather's size
+            unsigned char* nb_ = nullptr;
+            if (hipnote(h, hipMalloc((void**)&nb_, (size_t)block_bytes), "hipMalloc(result block)")) {
+                (void)hipnote(h, hipMemsetAsync(nb_, 0, (size_t)block_bytes, h->stream), "hipMemsetAsync");
+                (void)hipnote(h, hipMemcpyAsync(nb_, h->d_res, h->res_bytes, hipMemcpyDeviceToDevice, h->stream), "hipMemcpyAsync(loaded block)");
+                (void)hipnote(h, hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+                (void)hipFree(h->d_res);
+                h->d_res = nb_;
+                h->cap_res = (size_t)block_bytes;
+            } else use_own = false;
         }
         if (ok && use_own && (!h->d_res || h->cap_res < (size_t)block_bytes)) {
             if (h->planned) {

@@ -12,7 +12,10 @@
 //       form), which is also the text str(numpy.float64) gives.  Needs no GPU result: the band loop calls
 //       it while the pass is running.
 //   build_stdict(mask (B, VL, MB) uint8, nwin (B,) int64, pair_idx (P, 2) int32, nchans, keys flat list,
-//                into dict | None, k0)
+//                into dict | None, k0, cache | None, u0 = -1, u1 = -1)
+//       u0 <= u1 given: only the units [u0, u1) of the flattened (band, window) order are entered — the unit batches of
+//       a streamed pass arrive one after the other, each a range that may start and end inside a band; 'size' goes in
+//       with the range that holds the last window of the first band.
 //       -> dict (``into`` updated in place when given: the band groups of a pipelined call arrive one after the
 //       other; k0 = index in ``keys`` of this mask's first window), entries in (band, window) order, 'size' right after the first band's entries (the
 //       insertion order of the reference's merge loop).  Windows that dropped the SAME set of pairs
@@ -274,8 +277,8 @@ PyObject* new_pattern_cache(PyObject*, PyObject*) {
 PyObject* build_stdict(PyObject*, PyObject* args) {
     PyObject *mask_obj, *nwin_obj, *pair_obj, *keys, *into = Py_None, *cache_obj = Py_None;
     long nchans;
-    Py_ssize_t k0 = 0;
-    if (!PyArg_ParseTuple(args, "OOOlO|OnO", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys, &into, &k0, &cache_obj)) return nullptr;
+    Py_ssize_t k0 = 0, ru0 = -1, ru1 = -1;
+    if (!PyArg_ParseTuple(args, "OOOlO|OnOnn", &mask_obj, &nwin_obj, &pair_obj, &nchans, &keys, &into, &k0, &cache_obj, &ru0, &ru1)) return nullptr;
     if (into != Py_None && !PyDict_Check(into)) { PyErr_SetString(PyExc_TypeError, "into must be a dict or None"); return nullptr; }
     PatternCache* cache = nullptr;
     if (cache_obj != Py_None) {
@@ -321,7 +324,11 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
             PyErr_SetString(PyExc_ValueError, "build_stdict: inconsistent shapes (mask / nwin / pair_idx / keys)");
         } else {
             if (into != Py_None) { d = into; Py_INCREF(d); } else d = PyDict_New();
-            const bool fresh = d && PyDict_Size(d) == 0;     // 'size' goes right after the first band of the first group
+            const bool ranged = ru0 >= 0 && ru1 >= ru0;
+            // 'size' goes right after the first band of the first group; of a streamed pass: with the unit range that
+            // holds the first band's last window (or the first range, if that band has no windows)
+            const bool fresh = d && (ranged ? (B > 0 && ((ru0 < nwin[0] && nwin[0] <= ru1) || (nwin[0] == 0 && ru0 == 0)))
+                                            : PyDict_Size(d) == 0);
             size_obj = PyLong_FromLong(nchans);
             std::vector<int32_t> dropped((size_t)P);
             PatternCache local;
@@ -336,8 +343,20 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
             const uint8_t* last = nullptr;                            // run of equal masks: skip the lookup
             PyObject* last_arr = nullptr;
             Py_ssize_t k = k0;
-            for (npy_intp b = 0; b < B && d; ++b) {
-                for (int64_t w = 0; w < nwin[b] && d; ++w, ++k) {
+            Py_ssize_t uflat = 0;                                     // flat unit index of (b, 0)
+            for (npy_intp b = 0; b < B && d; uflat += (Py_ssize_t)nwin[b], ++b) {
+                int64_t wlo = 0, whi = nwin[b];
+                if (ranged) {
+                    if (uflat + nwin[b] <= ru0 || uflat >= ru1) {      // band outside the range
+                        k += (Py_ssize_t)nwin[b];
+                        if (b == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+                        continue;
+                    }
+                    if (ru0 > uflat) wlo = ru0 - uflat;
+                    if (ru1 < uflat + nwin[b]) whi = ru1 - uflat;
+                    k += (Py_ssize_t)wlo;
+                }
+                for (int64_t w = wlo; w < whi && d; ++w, ++k) {
                     const uint8_t* mm = m + ((size_t)b * VL + (size_t)w) * MB;
                     PyObject* arr = nullptr;
                     if (last && memcmp(last, mm, (size_t)MB) == 0) {
@@ -392,10 +411,11 @@ PyObject* build_stdict(PyObject*, PyObject* args) {
                         if (bad) { Py_CLEAR(d); break; }
                     } else if (PyDict_SetItem(d, PyList_GET_ITEM(keys, k), arr)) { Py_CLEAR(d); break; }
                 }
+                k += (Py_ssize_t)(nwin[b] - whi);
                 if (d && b == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
             }
             local.clear();                      // (a caller-held cache keeps its arrays)
-            if (d && B == 0 && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
+            if (d && B == 0 && !ranged && fresh && PyDict_SetItemString(d, "size", size_obj)) Py_CLEAR(d);
         }
     }
     Py_XDECREF(size_obj);

@@ -59,8 +59,19 @@ struct nbls_handle {
     hipStream_t up = nullptr;          // plan-time table uploads (highest priority, see alloc_copy)
     int stream_priority = 0;           // nbls_set_option("stream_priority")
     std::vector<hipEvent_t> pev;    // pipeline hand-off events
-    bool fuse_solve = false;        // set by nbls_execute_stages when correlation + solve run pipelined
+    bool fuse_solve = false;        // set by nbls_execute_stages: every unit batch of the correlation stage is followed by its solve
+    bool solve_on_stream2 = false;  // ... on the second stream (option "overlap"), else behind the batch on `stream`
     bool solve_done = false;
+    int last_stage_mask = 7;        // stages of the last pass (nbls_fetch zeroes the outputs of stages that did not run)
+
+    // ---- streamed results (nbls_stream_results): a pinned host mirror of the result block, filled batch by batch ----
+    bool stream_results = false;
+    unsigned char* h_res = nullptr; // pinned mirror of d_res
+    size_t cap_hres = 0;
+    hipStream_t cstream = nullptr;  // the D2H copies of the batches (a DMA engine beside the compute streams)
+    struct result_batch { int64_t u0, u1, c0, c1; };
+    std::vector<result_batch> rbatches;   // batches queued by the last nbls_execute*, in the order they finish
+    std::vector<hipEvent_t> rev;    // 2 per batch: [2k] rows complete on the producing stream, [2k+1] copy landed
     std::string err;
     std::mutex err_mu;                 // fail() may be called from the upload thread (nbls_upload_rows) too
     bool trace_loaded = false;         // samples behind the declared shape (nbls_set_trace_shape / nbls_upload_rows)
@@ -123,6 +134,7 @@ struct nbls_handle {
     //   MB = ceil(P/8), bit k & 7 of byte k >> 3 = weight of pair k (ceil(P/8) bytes per unit)
     unsigned char* d_res = nullptr;
     size_t cap_res = 0, res_bytes = 0;
+    bool res_loaded = false;       // d_res holds a block put there by nbls_load_result_block (cleared by the next nbls_plan)
     size_t reserve_res = 0;        // minimum allocation of the result block (nbls_reserve_results: equal gather blocks)
     // ---- RCCL gather (comm.hip) ----
     void* comm = nullptr;          // ncclComm_t
@@ -189,8 +201,9 @@ struct nbls_handle {
     bool prof = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    std::vector<hipEvent_t> bev;   // per-batch events of the screening path (4 per batch)
+    std::vector<hipEvent_t> bev;   // per-batch events of the screening path (5 per batch: quantize | screen | verify | solve)
     int bev_used = 0;
+    bool prof_fused = false;       // the last profiled pass ran its solves per batch (bev[5k+4] recorded)
     int xcorr_impl_used = 0;       // 1 VALU, 2 f64 MFMA, 3 int8 screening
     nbls_timings tim{};
 };
@@ -202,6 +215,8 @@ hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
 hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st);
+// streamed results: queue the copy of the rows of units [u0, u1) into the pinned mirror behind what `producer` has queued
+hipError_t nbls_queue_result_batch(nbls_handle* h, int64_t u0, int64_t u1, hipStream_t producer);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
 bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G);
 hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int64_t* launches_io);

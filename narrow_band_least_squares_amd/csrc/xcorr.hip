@@ -351,10 +351,17 @@ hipError_t nbls_launch_xcorr(nbls_handle* h) {
             used = u_ > used ? u_ : used;
             fallback_bands += g.b1 - g.b0;
             if (h->xcorr_impl != 3) ++launches;
+            // per-batch solves (nbls_execute_stages: fuse_solve): a window group that does not take the screening path
+            // is one batch of its own — without this its units were never solved (nbls_xcorr_screen_finish marks the
+            // solve stage done for the whole pass)
+            if (e == hipSuccess && h->fuse_solve) {
+                e = nbls_launch_solve_range(h, g.u0, g.u1 - g.u0, h->stream);
+                if (e == hipSuccess) e = nbls_queue_result_batch(h, g.u0, g.u1, h->stream);
+            }
         }
         if (e != hipSuccess) return e;
     }
-    if (h->xcorr_impl == 3 && any_screen) {
+    if (h->xcorr_impl == 3 && (any_screen || h->fuse_solve)) {
         h->xcorr_impl_used = 3;
         h->tim.xcorr_fallback_bands = fallback_bands;          // bands of this pass that ran on a general correlator
         return nbls_xcorr_screen_finish(h, launches);

@@ -1535,7 +1535,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     }
     const int64_t nbatch = (ue - ub + batch - 1) / batch;
     if (h->prof) {
-        while ((int64_t)h->bev.size() < 4 * (launches + nbatch)) {
+        while ((int64_t)h->bev.size() < 5 * (launches + nbatch)) {
             hipEvent_t ev;
             if (hipEventCreate(&ev) != hipSuccess) return hipErrorOutOfMemory;
             h->bev.push_back(ev);
@@ -1545,7 +1545,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
         a.u0 = (int)u0;
         a.nu = (int)((ue - u0) < batch ? (ue - u0) : batch);
         h->last_batch = a.nu;
-        hipEvent_t* ev = h->prof ? &h->bev[4 * launches] : nullptr;
+        hipEvent_t* ev = h->prof ? &h->bev[5 * launches] : nullptr;
         if (ev) (void)hipEventRecord(ev[0], h->stream);
         {
             const int gpl = (a.WP / 8 + 63) / 64;          // 8-sample groups per lane
@@ -1591,18 +1591,25 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);
         if (h->fuse_solve) {
-            // pipeline: the solve of this batch runs on the second stream (VALU-bound) while the next
-            // batch is quantised / screened (matrix pipe + LDS) on the first
-            while ((int64_t)h->pev.size() <= launches + 1) {
-                hipEvent_t pe;
-                if (hipEventCreateWithFlags(&pe, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
-                h->pev.push_back(pe);
+            // the solve of this batch right behind it: on the same stream (the batch's rows are complete, and on their
+            // way to the host, while the next batch is correlated), or — option "overlap" — on the second stream
+            // (VALU-bound) beside the next batch's quantiser / screening kernel (matrix pipe + LDS)
+            hipStream_t ss = h->stream;
+            if (h->solve_on_stream2) {
+                while ((int64_t)h->pev.size() <= launches + 1) {
+                    hipEvent_t pe;
+                    if (hipEventCreateWithFlags(&pe, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+                    h->pev.push_back(pe);
+                }
+                (void)hipEventRecord(h->pev[launches], h->stream);
+                (void)hipStreamWaitEvent(h->stream2, h->pev[launches], 0);
+                ss = h->stream2;
             }
-            (void)hipEventRecord(h->pev[launches], h->stream);
-            (void)hipStreamWaitEvent(h->stream2, h->pev[launches], 0);
-            hipError_t se = nbls_launch_solve_range(h, u0, a.nu, h->stream2);
+            hipError_t se = nbls_launch_solve_range(h, u0, a.nu, ss);
             if (se != hipSuccess) return se;
-        }
+            if (ev) (void)hipEventRecord(ev[4], ss);
+            if ((se = nbls_queue_result_batch(h, u0, u0 + a.nu, ss)) != hipSuccess) return se;
+        } else if (ev) (void)hipEventRecord(ev[4], h->stream);
         ++launches;
     }
     *launches_io = launches;
@@ -1615,7 +1622,8 @@ hipError_t nbls_xcorr_screen_finish(nbls_handle* h, int64_t launches) {
     // the correlation stage of this pass is queued: a pass chained behind it (nbls_execute_after) may start its own
     // correlation stage here — BEFORE the join below, so that it runs beside this pass's last solve
     if (h->ev_xd) { (void)hipEventRecord(h->ev_xd, h->stream); h->ev_xd_recorded = true; h->ev_xd_by_launcher = true; }
-    if (h->fuse_solve) {       // join: everything later on `stream` sees the solves
+    if (h->fuse_solve) h->solve_done = true;
+    if (h->solve_on_stream2) {       // join: everything later on `stream` sees the solves
         while ((int64_t)h->pev.size() <= launches) {
             hipEvent_t pe;
             if (hipEventCreateWithFlags(&pe, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
@@ -1623,9 +1631,8 @@ hipError_t nbls_xcorr_screen_finish(nbls_handle* h, int64_t launches) {
         }
         (void)hipEventRecord(h->pev[launches], h->stream2);
         (void)hipStreamWaitEvent(h->stream, h->pev[launches], 0);
-        h->solve_done = true;
     }
-    if (h->prof) h->bev_used = (int)(4 * launches);
+    if (h->prof) { h->bev_used = (int)(5 * launches); h->prof_fused = h->fuse_solve; }
     h->tim.xcorr_launches = launches;
     return hipGetLastError();
 }

@@ -67,6 +67,15 @@ def visible_devices():
     return list(range(load_library().nbls_device_count()))
 
 
+def set_transport_library(path, allow_shared_device=False):
+    """Rehearsal on a one-GPU box (``nbls_comm_set_library``): resolve RCCL's entry points from ``path`` — the tests'
+    loopback stand-in — and let one device carry several ranks.  Before the first communicator of the process."""
+    from ._hip import load_library
+    rc = load_library().nbls_comm_set_library(path.encode() if path else None, int(bool(allow_shared_device)))
+    if rc != 0:
+        raise RuntimeError('nbls_comm_set_library: RCCL has already been resolved from another library (%d)' % rc)
+
+
 class Group:
     """The ranks (= GPUs) one call is sharded over.  ``handles`` are the library handles THIS process
     drives (all of them in the one-process form, one in the process-per-GPU form); ``ranks`` their ranks."""

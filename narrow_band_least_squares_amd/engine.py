@@ -62,6 +62,29 @@ def pipeline_groups(nwin, npairs=28):
     return max(1, min(4, nb, int(np.sum(nwin) * weight) // 16000))
 
 
+_graveyard = []
+
+
+def release_later(*objs):
+    """Keep helper objects of a finished call alive until ``release_deferred`` (their teardown — tens of thousands of
+    small records — is host time that can hide behind the next call's GPU pass)."""
+    _graveyard.append(objs)
+
+
+def release_deferred():
+    del _graveyard[:]
+
+
+def streamed_default():
+    """Whether a whole call runs as ONE pass whose unit batches stream their rows to the host (``nbls_stream_results``)
+    instead of as several band groups on several handles: the default; ``NBLS_PIPELINE_GROUPS`` > 1 selects the band
+    groups of rounds 2-3, ``NBLS_STREAM_RESULTS=0`` one group without streaming."""
+    if os.environ.get('NBLS_STREAM_RESULTS', '1') == '0':
+        return False
+    env = os.environ.get('NBLS_PIPELINE_GROUPS')
+    return not (env and int(env) > 1)
+
+
 def stream_to_array(st):
     """-> (data (N, npts) float64 C-contiguous, fs, start date number)."""
     nchans = len(st)
@@ -310,7 +333,7 @@ def upload_trace(h, data, fs):
 
 
 def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0, trace_from=None,
-           trace_ready=False, after=None, before_execute=None):
+           trace_ready=False, after=None, before_execute=None, stream=False):
     """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
     None = all) on handle ``h``.  Returns as soon as the kernels are queued.  ``trace_from``: another handle of
     the same GPU that already holds this trace (device-to-device copy instead of a second upload).
@@ -341,6 +364,7 @@ def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl
             h.set_window_ranges(None)
     if before_execute is not None:
         before_execute()
+    h.stream_results(stream)             # (``stream``: the rows come back batch by batch, see ``process``)
     h.execute(after=after)
 
 
@@ -363,7 +387,7 @@ def split_block(block, nbands, vector_len, mask_bytes):
 def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
             filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
             want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
-            upload=True, window_slice=None, host_overlap=None, group_done=None, groups=None):
+            upload=True, window_slice=None, host_overlap=None, group_done=None, groups=None, units_done=None):
     """Run the hot path for a list of bands on one GPU.
 
     window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
@@ -378,7 +402,14 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     ``host_overlap(res)`` runs once everything is queued (filter responses, key strings: host work that needs
     no GPU result); ``group_done(res, b0, b1)`` runs as soon as the rows of bands [b0, b1) have landed, while
     later groups are still being computed (the caller builds its dictionary there).
-    More bands than fit in HBM at once are processed in consecutive rounds."""
+    More bands than fit in HBM at once are processed in consecutive rounds.
+
+    Default since round 4 (``streamed_default``; ``groups`` given or ``NBLS_PIPELINE_GROUPS`` > 1 select the band groups
+    above): ONE pass on one handle whose unit batches — consecutive (band, window) units, each a complete
+    correlate -> solve -> pack chain on the GPU — copy their rows into a pinned host mirror as they finish
+    (``nbls_stream_results``).  ``units_done(res, u0, u1)`` runs as soon as the rows of the units [u0, u1) (flat index
+    over all bands of the call, band-major) are in ``res``, while the GPU works on the next batch; without it
+    ``group_done`` is called for the bands a batch completes."""
     nchans, npts = _shape_of(data)
     nb = len(band_edges)
     cap = max_bands_per_pass(nchans, npts)
@@ -420,7 +451,8 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                                      filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
                                      group_done)
         cap = max(1, cap)
-        ngroups = 1 if (prefiltered or handle is not None or not upload) and groups is None else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
+        streamed = groups is None and window_slice is None and streamed_default()
+        ngroups = 1 if ((prefiltered or handle is not None or not upload) and groups is None) or streamed else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
         ngroups = max(1, min(ngroups, nb))
         # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
         # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
@@ -467,10 +499,40 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
 
         deferred = []                                 # rounds collected before host_overlap has run (sequential rounds)
 
+        cum_units = np.concatenate(([0], np.cumsum(nwin))).astype(np.int64)
+        done_band = [0]                               # bands [0, done_band) have been reported through group_done
+
+        def collect_streamed(h, b0, b1, notify):
+            # the rows arrive batch by batch (pinned mirror of the result block): copy each batch's cells out and tell
+            # the caller, while the GPU is busy with the next batch
+            for k in range(h.result_batches()):
+                u0, u1, c0, c1, gsrc, msrc = h.wait_result_batch(k)
+                if c1 > c0:
+                    for g in range(4):
+                        grids[g, b0:b1].reshape(-1)[c0:c1] = gsrc[g, c0:c1]
+                    mask[b0:b1].reshape(-1, MB)[c0:c1] = msrc[c0:c1]
+                if not notify:
+                    continue
+                g0, g1 = int(cum_units[b0]) + u0, int(cum_units[b0]) + u1
+                if units_done is not None:
+                    if g1 > g0:
+                        units_done(res, g0, g1)
+                elif group_done is not None:
+                    bd = int(np.searchsorted(cum_units, g1, side='right')) - 1     # bands complete up to unit g1
+                    bd = min(max(bd, done_band[0]), b1)
+                    if g1 >= cum_units[b1]:
+                        bd = b1
+                    if bd > done_band[0]:
+                        group_done(res, done_band[0], bd)
+                        done_band[0] = bd
+
         def collect(h, b0, b1, notify=True):
-            out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
-            grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
-            mask[b0:b1] = out['mask']
+            if streamed:
+                collect_streamed(h, b0, b1, notify)
+            else:
+                out = h.fetch_packed()                    # waits for that pass; ONE D2H copy (grids + weight mask)
+                grids[:, b0:b1] = np.stack((out['vel'], out['baz'], out['mdccm'], out['sigma_tau']))
+                mask[b0:b1] = out['mask']
             if want_lag or want_cmax or want_z:
                 ext = h.fetch(want_lag=want_lag, want_cmax=want_cmax, want_z=want_z, grids=False)
                 for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
@@ -478,6 +540,11 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                         arr[b0:b1] = ext[name]
             if not notify:
                 deferred.append((b0, b1))
+            elif streamed:
+                pass                                   # (told batch by batch above)
+            elif units_done is not None:
+                if cum_units[b1] > cum_units[b0]:
+                    units_done(res, int(cum_units[b0]), int(cum_units[b1]))
             elif group_done is not None:
                 group_done(res, b0, b1)
 
@@ -515,19 +582,24 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             launch(h, data, prep, upload=upload, window_slice=window_slice,
                    xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
                    trace_ready=early, after=launched[-1][0] if ordered else None,
-                   before_execute=upload_done if early else None)
+                   before_execute=upload_done if early else None, stream=streamed)
             launched.append((h, b0, b1))
             res.handle = h
     finally:
         if uploader is not None:                  # prepare() / plan raised: do not leave the copy running behind the caller
             uploader.join()
     # everything is queued: host work that needs no GPU result hides behind the passes
+    release_deferred()
     finish_skeleton(prep)
     if host_overlap is not None:
         host_overlap(res)
-    if group_done is not None:
-        for b0, b1 in deferred:                   # rounds that landed before the skeleton existed, in band order
+    for b0, b1 in deferred:                       # rounds that landed before the skeleton existed, in band order
+        if units_done is not None:
+            if cum_units[b1] > cum_units[b0]:
+                units_done(res, int(cum_units[b0]), int(cum_units[b1]))
+        elif group_done is not None:
             group_done(res, b0, b1)
+            done_band[0] = b1
     for item in launched:
         collect(*item)
     return res
@@ -594,7 +666,7 @@ def new_pattern_cache():
     return None
 
 
-def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0, cache=None):
+def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0, cache=None, units=None):
     """lts_array's dropped-element dictionary for ALL bands of a pass from the packed weight mask
     (B, VL, ceil(P/8)): key (``keys[b][w]``, see ``time_keys``) -> 1-based element numbers of both
     members of every zero-weight pair (first members, then second members), only for windows that
@@ -608,14 +680,44 @@ def stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0, cache=
     module built, one C++ pass does the work; the NumPy form below is its equivalent.
 
     ``into`` / ``k0``: update an existing dictionary with the bands of one group of a pipelined call (``k0`` =
-    index in ``keys`` of this mask's first window); 'size' is only placed by the call that starts the dictionary."""
+    index in ``keys`` of this mask's first window); 'size' is only placed by the call that starts the dictionary.
+
+    ``units=(u0, u1)``: enter only the units [u0, u1) of the flattened (band, window) order of ``mask`` / ``nwin`` (the
+    batches of a streamed pass; consecutive ranges in ascending order); 'size' goes in with the range that holds the
+    first band's last window."""
     if _hostext is not None:
+        u0, u1 = (-1, -1) if units is None else (int(units[0]), int(units[1]))
         return _hostext.build_stdict(np.ascontiguousarray(mask, dtype=np.uint8), np.ascontiguousarray(nwin, dtype=np.int64),
-                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys, into, int(k0), cache)
-    return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into, k0)
+                                     np.ascontiguousarray(pair_idx, dtype=np.int32), int(nchans), keys, into, int(k0), cache, u0, u1)
+    return _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into, k0, units)
 
 
-def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0):
+def _py_stdict_from_mask(mask, nwin, pair_idx, nchans, keys, into=None, k0=0, units=None):
+    if units is not None:
+        # a unit range: the bands it touches, cut at the end of the first band ('size' follows that band's entries)
+        u0, u1 = int(units[0]), int(units[1])
+        nw = np.asarray(nwin, dtype=np.int64)
+        cum = np.concatenate(([0], np.cumsum(nw)))
+        stdict = {} if into is None else into
+        B, VL, MB = mask.shape
+        flat_keys = keys
+        if isinstance(keys, tuple):
+            text, length = keys
+            flat_keys = [bytes(text[i, :length[i]]).decode('ascii') for i in range(len(length))]
+        full = np.packbits(np.ones(len(pair_idx), dtype=np.uint8), bitorder='little')
+        pidx = np.asarray(pair_idx)
+        for b in range(B):
+            lo, hi = max(u0, int(cum[b])), min(u1, int(cum[b + 1]))
+            for u in range(lo, hi):
+                m = mask[b, u - int(cum[b])]
+                if ((m & full) != full).any():
+                    cols = np.nonzero(np.unpackbits(m, bitorder='little')[:len(pidx)] == 0)[0]
+                    arr = np.concatenate((pidx[cols, 0] + 1, pidx[cols, 1] + 1)).astype((pidx[:1, 0] + 1).dtype, copy=False)
+                    arr.flags.writeable = False
+                    stdict[flat_keys[k0 + u]] = arr
+            if b == 0 and ((u0 < nw[0] <= u1) or (nw[0] == 0 and u0 == 0)):
+                stdict['size'] = nchans
+        return stdict
     if isinstance(keys, tuple):                                  # (text, length) of time_key_text
         text, length = keys
         keys = [bytes(text[i, :length[i]]).decode('ascii') for i in range(len(length))]

@@ -99,8 +99,22 @@ def _run_bands(bands, WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_list, freql
             engine.stdict_from_mask(res.mask[b0:b1], res.nwin[b0:b1], res.pair_idx, res.nchans, res.keys,
                                     into=res.stdict, k0=int(np.sum(res.nwin[:b0])), cache=res.pattern_cache)
 
+    def units_done(res, u0, u1):
+        # ... of the unit batch whose rows just landed (a streamed pass), while the GPU works on the next batch
+        if ALPHA < 1.0 and want_keys:
+            engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, res.nchans, res.keys, into=res.stdict,
+                                    cache=res.pattern_cache, units=(u0, u1))
+
     res = engine.process(rows, fs, t0, rij, edges, winlens, WINOVER, ALPHA, FILTER_TYPE, FILTER_ORDER,
-                         FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side, group_done=group_done)
+                         FILTER_RIPPLE, vector_len=vector_len, host_overlap=host_side, group_done=group_done,
+                         units_done=units_done)
+    if ALPHA < 1.0 and want_keys and 'size' not in res.stdict:
+        res.stdict['size'] = res.nchans            # (no band had a window: lts_array's dictionary still names the array size)
+    if ALPHA < 1.0 and want_keys:
+        # the helper objects of the dictionary (2*10^4 pattern records, 2.7 MB of key text at the benchmark's shape) are
+        # taken apart by the NEXT call of this process behind its GPU pass, or at exit — not between the last row's
+        # arrival and the return of this call
+        engine.release_later(res.__dict__.pop('pattern_cache', None), res.__dict__.pop('keys', None))
     return res, out_rows['w'], out_rows['h']
 
 
@@ -131,7 +145,7 @@ def narrow_band_least_squares(WINLEN_list, WINOVER, ALPHA, st, lat_list, lon_lis
         sig_tau_array = res.sigma_tau
     else:
         stdict_all = res.stdict                  # built group by group while the GPU was still working
-        sig_tau_array = np.zeros_like(res.sigma_tau)
+        sig_tau_array = np.zeros(res.sigma_tau.shape)          # (calloc: no pages touched)
     return (res.vel, res.baz, res.mdccm, res.t, stdict_all, sig_tau_array, num_compute_list,
             w_array, h_array)
 

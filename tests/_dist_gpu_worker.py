@@ -5,8 +5,8 @@ Runs in its own process because a communicator, once made, lives as long as the 
   mode 'rank'  process-per-GPU form with a one-rank world: the 128-byte id, ncclCommInitRank, all-gather
   mode 'loopN' (N = 2, 3): N RANKS of one process on this box's one GPU — N library handles, N launch threads, N result
                blocks in HBM, nbls_comm_gather with root 0 — over the loopback stand-in of tests/c_caller/loopback_rccl.cpp
-               (device-to-device copies where RCCL would use xGMI; the caller set NBLS_RCCL_LIB, NBLS_ALLOW_SHARED_DEVICE,
-               NBLS_DEVICES=0,0[,0])
+               (device-to-device copies where RCCL would use xGMI; the caller names it in NBLS_TEST_TRANSPORT — read HERE and handed
+               to the library through nbls_comm_set_library, the library itself reads no environment — and sets NBLS_DEVICES=0,0[,0])
   mode 'procfail'  the same launcher form, with rank 1 failing before it can plan (status word, nobody hangs), then a healthy call
   mode 'proc'  one PROCESS per rank under a launcher (python -m torch.distributed.run --nproc-per-node 2 ...), all of them
                on this box's one GPU (NBLS_DEVICE=0): the id over the TCP side channel, ncclCommInitRank with a world of
@@ -27,6 +27,8 @@ def main():
     from narrow_band_least_squares_amd import (narrow_band_least_squares, narrow_band_least_squares_parallel,
                                                synthetic, dist, engine)
     assert 'torch' not in sys.modules
+    if os.environ.get('NBLS_TEST_TRANSPORT'):
+        dist.set_transport_library(os.environ['NBLS_TEST_TRANSPORT'], allow_shared_device=True)
     if mode == 'rank':
         # what dist.get_group() does for WORLD_SIZE > 1, with a world of one
         import ctypes as C

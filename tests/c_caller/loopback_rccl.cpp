@@ -6,7 +6,7 @@
 // A second form serves ranks that are separate PROCESSES on that one GPU (the launcher form: python -m
 // torch.distributed.run --nproc-per-node 2 ...): ncclCommInitRank with a world > 1 maps a file under /dev/shm named
 // after the unique id, and the all-gather goes device -> shared host memory -> device with arrive / depart counters.
-// Selected with NBLS_RCCL_LIB=<this .so> (comm.hip tries that name first) and NBLS_ALLOW_SHARED_DEVICE=1.
+// Selected with nbls_comm_set_library(<this .so>, 1) (dist.set_transport_library; bench.py --transport-lib).
 //   hipcc -O2 -shared -fPIC tests/c_caller/loopback_rccl.cpp -o tests/c_caller/libloopback_rccl.so
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

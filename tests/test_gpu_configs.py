@@ -279,6 +279,26 @@ def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
         np.testing.assert_allclose(got.vel[b, :n], out[0], rtol=1e-9)
         np.testing.assert_allclose(got.baz[b, :n], out[1], rtol=1e-9)
         np.testing.assert_allclose(got.mdccm[b, :n], out[3], rtol=1e-9)
+    # with the solves per unit batch (option "overlap", and every streamed pass) the band on the general
+    # correlator was never solved — all-zero rows with rc OK.  Same rows now, whichever way the solves are scheduled.
+    ref_rows = {k: getattr(got, k).copy() for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'lag')}
+    r0 = rij - rij.mean(axis=1, keepdims=True)
+    for alpha in (1.0, 0.5):
+        base = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True, groups=1)
+        if alpha == 1.0:
+            for k, v in ref_rows.items():
+                np.testing.assert_array_equal(getattr(base, k), v)
+        assert np.all(base.vel[0, :int(base.nwin[0])] > 0)
+        try:
+            h.set_option('overlap', 1)
+            ov = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True, groups=1)
+            st_ov = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True)
+        finally:
+            h.set_option('overlap', 0)
+        st = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True)
+        for other in (ov, st_ov, st):
+            for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'lag', 'z', 'mask'):
+                np.testing.assert_array_equal(getattr(other, k), getattr(base, k), err_msg=k)
 
 
 @pytest.mark.parametrize('ftype,alpha', [('butter', 1.0), ('cheby1', 0.5)])

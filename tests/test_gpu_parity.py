@@ -338,6 +338,117 @@ def test_kernel_variants_agree(monkeypatch):
         np.testing.assert_array_equal(getattr(r_mfma, k), getattr(r_gen, k))
 
 
+@pytest.mark.parametrize('alpha', [0.5, 1.0])
+def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
+    """The default whole call since round 4 (nbls_stream_results): every unit batch a complete correlate -> solve -> pack
+    chain whose rows reach a pinned host mirror while the next batch runs.  With a screening batch small enough for a
+    dozen batches that cut through bands: rows, lags, weights and the dictionary bit-identical to the pass fetched in one
+    piece, to the band groups of rounds 2-3, and to the solve on the second stream (option "overlap")."""
+    c = _cfg('cfg2', 0.25)
+    fr = np.logspace(-2, 1, 24)
+    w = np.zeros(24)
+    nb = 9
+    args = (c['WINLEN_list'][:nb], 0.5, alpha, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1], 'log', fr, 'butter', 2, 0.01)
+    h = engine.get_handle()
+    monkeypatch.delenv('NBLS_PIPELINE_GROUPS', raising=False)
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '0')
+    whole = narrow_band_least_squares(*args, rij=c['rij'])
+    monkeypatch.setenv('NBLS_PIPELINE_GROUPS', '3')
+    grouped = narrow_band_least_squares(*args, rij=c['rij'])
+    monkeypatch.delenv('NBLS_PIPELINE_GROUPS')
+    monkeypatch.delenv('NBLS_STREAM_RESULTS')
+    outs = {}
+    try:
+        h.set_option('screen_batch_mb', 1)
+        outs['streamed'] = narrow_band_least_squares(*args, rij=c['rij'])
+        nbatch = h.result_batches()
+        assert nbatch >= 3, nbatch
+        h.set_option('overlap', 1)
+        outs['overlap'] = narrow_band_least_squares(*args, rij=c['rij'])
+        # the engine-level entry with the side arrays (fetched after the last batch)
+        data, fs, t0 = engine.stream_to_array(c['st'])
+        edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in range(nb)]
+        kw = dict(want_lag=True, want_cmax=True, want_z=True)
+        seen = []
+        r_s = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'][:nb], 0.5, alpha, 'butter', 2, 0.01,
+                             units_done=lambda res, u0, u1: seen.append((u0, u1)), **kw)
+        h.set_option('overlap', 0)
+        h.set_option('screen_batch_mb', 192)
+        r_w = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'][:nb], 0.5, alpha, 'butter', 2, 0.01, groups=1, **kw)
+    finally:
+        h.set_option('overlap', 0)
+        h.set_option('screen_batch_mb', 192)
+    assert len(seen) >= 3 and seen[0][0] == 0 and seen[-1][1] == int(r_s.nwin.sum())
+    assert all(a[1] == b[0] for a, b in zip(seen[:-1], seen[1:]))              # consecutive, in order
+    for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'mask', 'lag', 'cmax', 'z', 't'):
+        np.testing.assert_array_equal(getattr(r_s, k), getattr(r_w, k), err_msg=k)
+    for name, got in list(outs.items()) + [('grouped', grouped)]:
+        assert got[6] == whole[6]
+        for i in (0, 1, 2, 3, 5, 7, 8):
+            np.testing.assert_array_equal(got[i], whole[i], err_msg='%s[%d]' % (name, i))
+        if alpha == 1.0:
+            assert got[4] is None
+        else:
+            assert list(got[4].keys()) == list(whole[4].keys()), name
+            for k in whole[4]:
+                np.testing.assert_array_equal(got[4][k], whole[4][k])
+
+
+def test_streamed_batches_through_the_c_abi():
+    """nbls_stream_results / nbls_result_batches / nbls_wait_result_batch as a C caller uses them: the cells of a batch in
+    the pinned mirror equal the same cells of nbls_fetch_packed, batch by batch; a pass on a general correlator (no unit
+    batches) is ONE batch; without nbls_stream_results there is nothing to wait for."""
+    c = _cfg('cfg2', 0.2)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    nb = 6
+    edges = [(c['freqlist'][b], c['freqlist'][b + 1]) for b in range(nb)]
+    prep = engine.prepare(data.shape[0], data.shape[1], fs, c['rij'], edges, c['WINLEN_list'][:nb], 0.5, 0.5, 'butter', 2, 0.01)
+    h = engine.get_handle()
+    try:
+        h.set_option('screen_batch_mb', 1)
+        engine.launch(h, data, prep, stream=True)
+        n = h.result_batches()
+        assert n >= 2
+        got = [h.wait_result_batch(k) for k in range(n)]
+        grids_m = got[-1][4].copy()
+        mask_m = got[-1][5].copy()
+        full = h.fetch_packed()
+        fg = np.stack([full[k].reshape(-1) for k in ('vel', 'baz', 'mdccm', 'sigma_tau')])
+        fm = full['mask'].reshape(-1, full['mask'].shape[2])
+        U = int(prep.nwin.sum())
+        assert got[0][0] == 0 and got[-1][1] == U
+        covered = np.zeros(fg.shape[1], dtype=bool)
+        for (u0, u1, c0, c1, _, _) in got:
+            assert u1 > u0 and c1 - c0 >= u1 - u0
+            covered[c0:c1] = True
+            np.testing.assert_array_equal(grids_m[:, c0:c1], fg[:, c0:c1])
+            np.testing.assert_array_equal(mask_m[c0:c1], fm[c0:c1])
+        assert np.all(fg[:, ~covered] == 0.0)                    # what no batch covers is padding
+        # general correlator: one batch with everything
+        engine.launch(h, data, prep, xcorr_impl=1, stream=True)
+        assert h.result_batches() == 1
+        u0, u1, c0, c1, g1, m1 = h.wait_result_batch(0)
+        assert (u0, u1) == (0, U)
+        g1 = g1.copy()
+        full1 = h.fetch_packed()
+        np.testing.assert_array_equal(g1[:, c0:c1], np.stack([full1[k].reshape(-1) for k in ('vel', 'baz', 'mdccm', 'sigma_tau')])[:, c0:c1])
+        np.testing.assert_allclose(g1[:, c0:c1], fg[:, c0:c1], rtol=1e-12)        # (another correlator: maxima to rounding)
+        engine.launch(h, data, prep)                             # not streamed
+        assert h.result_batches() == 0
+        with pytest.raises(_hip.NblsError):
+            h.wait_result_batch(0)
+        h.sync()
+        # ADVICE r03: the side arrays are not cleared by a pass; a pass WITHOUT the correlation / solve stages must not hand
+        # back the previous pass's lags and weights
+        assert np.any(h.fetch(want_lag=True, grids=False)['lag'] != 0)
+        h.execute(stages=1)
+        side = h.fetch(want_lag=True, want_cmax=True, want_weights=True, want_z=True)
+        for k in ('lag', 'cmax', 'weights', 'z', 'vel'):
+            assert not np.any(side[k]), k
+    finally:
+        h.set_option('screen_batch_mb', 192)
+
+
 @pytest.mark.parametrize('nchans,winlen', [(3, 20.0), (4, 12.5), (5, 30.0), (7, 9.0), (9, 25.0), (12, 15.0), (16, 40.0),
                                            (17, 10.0), (20, 12.0), (32, 15.0), (6, 12.525), (8, 12.175), (8, 51.3), (20, 60.0), (12, 70.0)])
 def test_correlators_agree_for_any_array_size(nchans, winlen):
@@ -558,7 +669,7 @@ def _loopback_env():
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
         subprocess.run(['/opt/rocm/bin/hipcc', '-O2', '-shared', '-fPIC', '--offload-arch=gfx950', src, '-o', lib], check=True, timeout=300)
     env = dict(os.environ)
-    env.update(NBLS_RCCL_LIB=lib, NBLS_ALLOW_SHARED_DEVICE='1')
+    env.update(NBLS_TEST_TRANSPORT=lib)        # read by tests/_dist_gpu_worker.py; bench.py takes --transport-lib
     return root, env
 
 
@@ -589,7 +700,7 @@ def test_bench_drives_two_ranks_without_a_launcher_over_the_loopback_transport()
     root, env = _loopback_env()
     env['NBLS_DEVICES'] = '0,0'
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'cfg2', '--steps', '2', '--warmup', '1',
-           '--no-cpu-baseline', '--no-noise']
+           '--no-cpu-baseline', '--no-noise', '--transport-lib', env['NBLS_TEST_TRANSPORT']]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -637,7 +748,7 @@ def test_bench_under_the_launcher_with_two_ranks_over_the_loopback_transport():
     root, env = _loopback_env()
     env['NBLS_DEVICE'] = '0'
     r = _launch_two_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'cfg2', '--steps', '2', '--warmup', '1',
-                           '--no-noise'], env, 29743)
+                           '--no-noise', '--transport-lib', env['NBLS_TEST_TRANSPORT']], env, 29743)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]

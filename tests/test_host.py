@@ -278,6 +278,7 @@ def test_sequential_rounds_build_the_dictionary_after_the_skeleton(monkeypatch):
     monkeypatch.setattr(engine, 'get_handle', lambda device=None, slot=0: hstub)
     data = c['data']
     monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr(2.5 * 8 * data.size / 2.0 ** 30))          # two bands per pass
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '0')            # (the streamed form of the rounds: next test)
     assert engine.max_bands_per_pass(*data.shape) == 2
     fr = np.logspace(-2, 1, 16)
     w = np.zeros(16)
@@ -291,6 +292,115 @@ def test_sequential_rounds_build_the_dictionary_after_the_skeleton(monkeypatch):
     for b in range(nb):
         first = next(k for k in keys if k.startswith('%02d_' % (b + 1)))
         np.testing.assert_array_equal(np.sort(stdict[first]), np.sort(pair_idx[b % 15] + 1))
+
+
+def test_streamed_pass_builds_rows_and_dictionary_batch_by_batch(monkeypatch):
+    """The default whole call since round 4: ONE pass whose unit batches arrive one after the other (engine.process with
+    ``nbls_stream_results``).  Stand-in handle (no GPU) that hands out batches cutting through bands: the rows and the
+    dictionary must equal those of the unstreamed call, entries in band order, 'size' behind the first band."""
+    from narrow_band_least_squares_amd import engine, synthetic
+    from narrow_band_least_squares_amd.narrow_band_least_squares import narrow_band_least_squares
+    c = synthetic.build_config('cfg2', 0.1)
+    nb = 5
+    rng = np.random.default_rng(11)
+
+    class StubHandle:
+        def set_trace_shape(self, *a): pass
+        def upload_rows(self, rows): pass
+
+    hstub = StubHandle()
+    waited = []
+
+    def fake_launch(h, data, prep, **kw):
+        before = kw.get('before_execute')
+        if before is not None:
+            before()
+        h.streamed = bool(kw.get('stream'))
+        B, VL, MB, P = prep.nbands, prep.vector_len, prep.mask_bytes, prep.npairs
+        w = (rng.random((B, VL, P)) > 0.1).astype(np.uint8)
+        mask = np.packbits(w, axis=-1, bitorder='little')
+        g = rng.random((4, B, VL))
+        for b in range(B):
+            g[:, b, prep.nwin[b]:] = 0.0
+            mask[b, prep.nwin[b]:] = 0
+        h.out = dict(vel=g[0], baz=g[1], mdccm=g[2], sigma_tau=g[3], mask=mask)
+        h.nwin, h.VL = [int(x) for x in prep.nwin], VL
+    hstub.fetch_packed = lambda: hstub.out
+
+    def batches():
+        U = sum(hstub.nwin)
+        cuts = sorted({0, U} | {int(x) for x in (0.13 * U, 0.5 * U, 0.51 * U, 0.9 * U)})
+        return list(zip(cuts[:-1], cuts[1:]))
+
+    def cell(u):
+        off = 0
+        for b, n in enumerate(hstub.nwin):
+            if u < off + n:
+                return b * hstub.VL + (u - off)
+            off += n
+        raise AssertionError
+
+    hstub.result_batches = lambda: len(batches())
+
+    def wait_result_batch(k):
+        u0, u1 = batches()[k]
+        waited.append(k)
+        c0, c1 = cell(u0), cell(u1 - 1) + 1
+        o = hstub.out
+        gsrc = np.full((4, len(hstub.nwin) * hstub.VL), np.nan)           # cells of other batches are undefined
+        msrc = np.full((len(hstub.nwin) * hstub.VL, o['mask'].shape[2]), 0x55, dtype=np.uint8)
+        for i, name in enumerate(('vel', 'baz', 'mdccm', 'sigma_tau')):
+            gsrc[i, c0:c1] = o[name].reshape(-1)[c0:c1]
+        msrc[c0:c1] = o['mask'].reshape(-1, o['mask'].shape[2])[c0:c1]
+        return u0, u1, c0, c1, gsrc, msrc
+    hstub.wait_result_batch = wait_result_batch
+    monkeypatch.setattr(engine, 'launch', fake_launch)
+    monkeypatch.setattr(engine, 'get_handle', lambda device=None, slot=0: hstub)
+    monkeypatch.delenv('NBLS_PIPELINE_GROUPS', raising=False)
+    fr = np.logspace(-2, 1, 16)
+    w = np.zeros(16)
+    args = (c['WINLEN_list'][:nb], 0.5, 0.5, c['st'], None, None, nb, w, w, c['freqlist'][:nb + 1], 'log', fr, 'butter', 2, 0.01)
+    out = narrow_band_least_squares(*args, rij=c['rij'])
+    assert hstub.streamed and waited == list(range(len(batches())))
+    o = hstub.out
+    np.testing.assert_array_equal(out[0], o['vel'])
+    np.testing.assert_array_equal(out[1], o['baz'])
+    np.testing.assert_array_equal(out[2], o['mdccm'])
+    keys = engine.time_keys(out[3], out[6], ['%02d_' % (b + 1) for b in range(nb)])
+    exp = engine._py_stdict_from_mask(o['mask'], np.array(out[6]), planner.pair_table(6), 6, keys)
+    assert list(out[4].keys()) == list(exp.keys())
+    for k in exp:
+        if k != 'size':
+            np.testing.assert_array_equal(out[4][k], exp[k])
+    # more bands than the HBM budget of one pass: streamed rounds one after the other, dictionary in band order
+    data = c['data']
+    monkeypatch.setenv('NBLS_MAX_FILTERED_GB', repr(2.5 * 8 * data.size / 2.0 ** 30))          # two bands per pass
+    outs = []
+    real_fake = fake_launch
+
+    def recording_launch(h, data, prep, **kw):
+        real_fake(h, data, prep, **kw)
+        outs.append(h.out)
+    monkeypatch.setattr(engine, 'launch', recording_launch)
+    del waited[:]
+    out3 = narrow_band_least_squares(*args, rij=c['rij'])
+    assert len(outs) == 3 and hstub.streamed
+    m_all = np.concatenate([x['mask'] for x in outs])
+    np.testing.assert_array_equal(out3[0], np.concatenate([x['vel'] for x in outs]))
+    exp3 = engine._py_stdict_from_mask(m_all, np.array(out3[6]), planner.pair_table(6), 6, keys)
+    assert list(out3[4].keys()) == list(exp3.keys())
+    for k in exp3:
+        if k != 'size':
+            np.testing.assert_array_equal(out3[4][k], exp3[k])
+    monkeypatch.delenv('NBLS_MAX_FILTERED_GB')
+    monkeypatch.setattr(engine, 'launch', fake_launch)
+    # the same through the band-group path (NBLS_STREAM_RESULTS=0): not streamed, same kind of result
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '0')
+    monkeypatch.setenv('NBLS_PIPELINE_GROUPS', '1')
+    del waited[:]
+    out2 = narrow_band_least_squares(*args, rij=c['rij'])
+    assert not hstub.streamed and not waited
+    np.testing.assert_array_equal(out2[0], hstub.out['vel'])
 
 
 def test_bench_refuses_what_it_cannot_measure():
@@ -403,6 +513,22 @@ def test_host_extension_matches_python_equivalents():
                 for k in exp:
                     if k != 'size':
                         np.testing.assert_array_equal(inc[k], exp[k])
+            # built unit batch by unit batch (streamed pass): ranges that start and end inside bands, one of them empty, some
+            # of them inside the first band — same dictionary, same order, 'size' behind the first band's entries
+            tot = int(nwin.sum())
+            for cuts in ((0, 5, 36, 37, 38, 70, 70, tot), (0, tot), (0, 37, tot), (0, 40, tot)):
+                for impl in (ext.build_stdict, engine._py_stdict_from_mask):
+                    inc = {}
+                    for u0, u1 in zip(cuts[:-1], cuts[1:]):
+                        if impl is ext.build_stdict:
+                            ret = impl(mask, nwin, pair_idx, nch, keys, inc, 0, None, u0, u1)
+                        else:
+                            ret = impl(mask, nwin, pair_idx, nch, keys, inc, 0, (u0, u1))
+                        assert ret is inc
+                    assert list(inc.keys()) == list(exp.keys()), (cuts, impl)
+                    for k in exp:
+                        if k != 'size':
+                            np.testing.assert_array_equal(inc[k], exp[k])
             # value arrays shared across the groups' calls through a caller-held cache: same dictionary, and a pattern
             # that shows up in two groups is ONE object
             cache = ext.new_pattern_cache()

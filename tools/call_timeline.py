@@ -28,9 +28,14 @@ def wrap(obj, name, label=None):
     setattr(obj, name, g)
 
 
-for n in ('prepare', 'launch', 'time_keys', 'stdict_from_mask', 'upload_trace'):
+for n in ('prepare', 'launch', 'time_keys', 'time_key_text', 'stdict_from_mask', 'upload_trace', 'stream_rows', 'new_stdict'):
     wrap(engine, n)
-for n in ('plan', 'execute', 'fetch_packed', 'set_trace_from'):
+nbm = sys.modules['narrow_band_least_squares_amd.narrow_band_least_squares']
+wrap(nbm, '_run_bands')
+wrap(engine, 'process')
+wrap(planner, 'sosfreqz_bands')
+wrap(planner, 'design_bandpass_many')
+for n in ('plan', 'execute', 'fetch_packed', 'set_trace_from', 'wait_result_batch', 'upload_rows', 'set_geometry', 'set_trace_shape'):
     wrap(_hip.Handle, n, 'handle.' + n)
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'

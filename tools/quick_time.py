@@ -23,6 +23,8 @@ def main():
     impl = int(opts.pop('impl', 0))
     nbands = int(opts.pop('bands', 0))
     noise = int(opts.pop('noise', 0))
+    gap_ms = float(opts.pop('gap_ms', 0))        # idle time between the passes (clock ramp-down experiment)
+    stream = int(opts.pop('stream', 0))          # stream=1: the pass as a whole call runs it (per-batch solves, rows streamed to the host)
     c = synthetic.build_config(name, scale=scale)
     rows, fs, t0 = engine.stream_rows(c['st'])
     if noise:          # incoherent white noise of the same shape (no common signal)
@@ -37,10 +39,13 @@ def main():
     h.set_profiling(True)
     prep = engine.prepare(len(rows), len(rows[0]), fs, c['rij'], edges, c['WINLEN_list'][:nb], c['overlap'], c['alpha'],
                           c['ftype'], c['order'], c['ripple'])
-    engine.launch(h, rows, prep, xcorr_impl=impl)
+    engine.launch(h, rows, prep, xcorr_impl=impl, stream=bool(stream))
     h.sync()
     U = int(prep.nwin.sum())
+    import time
     for r in range(reps):
+        if gap_ms:
+            time.sleep(gap_ms * 1e-3)
         h.execute()
         h.sync()
         tm = h.timings()
