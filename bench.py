@@ -118,6 +118,55 @@ def cpu_baseline(c, edges, winlens, budget_s=8.0):
                       'joblib one band per core' % (nb, seconds, sum(counts), n1)}
 
 
+def ltsva_entry(args):
+    """The step either side of the hot path: the broadband call of example.py:108-109,
+    ``stf, Fs, sos = filter_data(st, FILTER_TYPE, FMIN, FMAX, ...)`` then ``ltsva(stf, lat, lon, WINLEN, WINOVER, ALPHA)``
+    with WINLEN = 50 s (example.py:60) over the whole band of the configuration, all eight returns (the last two — the
+    confidence intervals — computed on the GPU behind the solve).  A step = both calls; the two legs are also timed apart."""
+    import io
+    from narrow_band_least_squares_amd import filter_data, ltsva
+    c = synthetic.build_config(args.config, scale=args.scale)
+    st, rij, fs = c['st'], c['rij'], c['fs']
+    fmin, fmax, winlen = c['freqlist'][0], c['freqlist'][-1], 50.0
+    h = engine.get_handle()
+
+    def one():
+        t0 = time.perf_counter()
+        stf, _, _ = filter_data(st, c['ftype'], fmin, fmax, c['order'], c['ripple'])
+        t1 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = ltsva(stf, None, None, winlen, c['overlap'], c['alpha'], False, rij=rij)
+        return out, (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+    for _ in range(args.warmup):
+        one()
+    h.sync()
+    tf, tl, held = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, a_, b_ = one()
+        tf.append(a_)
+        tl.append(b_)
+        held.append(out)
+    h.sync()
+    el = time.perf_counter() - t0
+    n = len(out[0])
+    line = {'metric': '(window x band) LTS solves/sec, 8-element synthetic', 'entry': 'ltsva (broadband filter_data -> ltsva, example.py:108-109)',
+            'value': n * args.steps / el, 'unit': 'solves/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': el / args.steps * 1e3, 'filter_data_ms_median': float(np.median(tf)), 'ltsva_ms_median': float(np.median(tl)),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': LABELS.get(args.config, args.config) + ' — ONE band %.3g-%.3g Hz, %s order %d, %g s windows %d%% overlap, alpha %g'
+                                   % (fmin, fmax, c['ftype'], c['order'], winlen, int(round(c['overlap'] * 100)), c['alpha']),
+                       'step': 'filter_data (upload, GPU filter + taper, the filtered stream back on the host) then ltsva (upload of the filtered '
+                               'stream, correlation, solve, confidence intervals on the GPU, dictionary)',
+                       'units_per_call': n, 'elements': len(st), 'window_samples': int(winlen * fs), 'scale': args.scale},
+            'uncertainty': {'vel_uncert_median_km_s': float(np.nanmedian(out[6])), 'baz_uncert_median_deg': float(np.nanmedian(out[7])),
+                            'where': 'GPU: uncertainty_kernel behind the solve (csrc/solve.hip); no host loop over windows'},
+            'roofline': None, 'cpu_baseline': None,
+            'note': 'a one-band call: PCIe-bound (the trace goes up twice and the filtered stream comes down once: 3 x 8 N npts bytes); '
+                    'roofline / cpu_baseline ride on the narrow-band line (--entry nbls)'}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -132,6 +181,10 @@ def main():
     ap.add_argument('--independent-calls', choices=['auto', 'on', 'off'], default='auto',
                     help='after the main measurement, time one whole single-GPU call per rank on the rank\'s own trace '
                          '(no collective; extra field `independent_calls`).  auto: in band-sharded runs under a launcher')
+    ap.add_argument('--entry', default='nbls', choices=['nbls', 'ltsva'],
+                    help='nbls (default): the narrow-band call of the metric.  ltsva: the broadband route of example.py:108-109 — '
+                         'filter_data(st, ...) then ltsva(stf, ...) over the configuration\'s trace (one band, WINLEN = 50 s), '
+                         'with the confidence intervals; its own JSON line, never BENCH\'s `value` of the narrow-band metric')
     ap.add_argument('--transport-lib', default=None,
                     help='REHEARSAL ONLY (one-GPU box): a library with RCCL\'s ten entry points to use instead of RCCL, several '
                          'ranks on one device (tests/c_caller/loopback_rccl.cpp); the numbers of such a run mean nothing')
@@ -178,6 +231,10 @@ def main():
         os.environ.setdefault('NBLS_DEVICES', ','.join(str(d) for d in range(ngpu)))
         os.environ['NBLS_DEVICES'] = ','.join(os.environ['NBLS_DEVICES'].split(',')[:ngpu])
     shard_traces = world > 1 and args.shard == 'traces'
+    if args.entry == 'ltsva':
+        if ngpu != 1:
+            give_up('--entry ltsva is a single-GPU measurement')
+        return ltsva_entry(args)
 
     seed = synthetic.SEED + 1 + (rank if shard_traces else 0)
     c = synthetic.build_config(args.config, scale=args.scale, trace_seed=seed)
@@ -284,7 +341,7 @@ def main():
         prep = engine.prepare(nchans, npts, fs_, rij, [edges[b] for b in my], [winlens[b] for b in my], c['overlap'],
                               c['alpha'], c['ftype'], c['order'], c['ripple'])
         h.set_profiling(True)
-        engine.launch(h, rows, prep)
+        engine.launch(h, rows, prep, stream=engine.streamed_default())     # (as a whole call runs it: per-batch solves, rows streamed)
         h.sync()
         kern, stages = [], []
         for _ in range(steps):
@@ -399,7 +456,8 @@ def main():
             try:
                 tj = json.load(open(tfile)).get(args.config)
                 if tj:
-                    traffic = float(tj['xcorr_hbm_bytes_per_launch'])
+                    # per PASS (the sum over the pass's launches of the kernel), like `achieved`: VERDICT r03 item 7
+                    traffic = float(tj['xcorr_hbm_bytes_per_pass']) if 'xcorr_hbm_bytes_per_pass' in tj else float(tj['xcorr_hbm_bytes_per_launch']) * int(stages[-1]['xcorr_launches'])
                     traffic_src = 'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (%s)' % tj.get('tag', 'r02')
             except Exception:
                 traffic = None
@@ -432,7 +490,8 @@ def main():
                          'xcorr_quantize': mean('quantize_ms'), 'xcorr_screen': mean('screen_ms'),
                          'xcorr_verify': mean('verify_ms')},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / peak, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
+                         'frac': achieved_tf / peak, 'traffic': traffic, 'traffic_unit': 'bytes per pass (all launches of the kernel in one pass)',
+                         'traffic_source': traffic_src, 'kernel': kname,
                          'kernel_ms_per_step': kern_ms, 'launches_per_step': launches,
                          'kernel_ms_in_call': in_call.get('screen_ms') if impl_used == 3 else in_call.get('xcorr_ms'),
                          'frac_in_call': (flop_total / (in_call['screen_ms'] * 1e-3) / 1e12 / peak) if (impl_used == 3 and in_call.get('screen_ms')) else None,

@@ -169,6 +169,19 @@ int nbls_sync(nbls_handle* h);
 int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* sigma_tau,
                int32_t* nwin, int32_t* lag, double* cmax, uint8_t* weights, double* z);
 
+/* Confidence intervals of the slowness estimate — the 7th / 8th returns of ltsva (vel_uncert, baz_uncert at
+ * narrow_band_least_squares.py:91, example.py:109; Szuberla & Olson 2004 as used by lts_array): half the spread of the
+ * trace velocity over the 90 % confidence ellipse of the slowness vector (semi-axes sqrt(chi2_{0.90,2}) sigma_tau /
+ * sqrt(lambda_i) along the eigenvectors of X^T X) and half the angle the ellipse subtends at the origin (NaN when the
+ * origin is inside).  Computed on the GPU behind every unit's solve when wanted:
+ *   nbls_set_uncertainty(h, eig6)   eig6 = {lambda_0, lambda_1 (ascending), R00, R01, R10, R11}: eigenvalues of X^T X
+ *                                   and the rotation into its eigen-frame (c = R z); NULL switches it off (default:
+ *                                   the band loop discards these two returns).  Read by the next nbls_plan.
+ *   nbls_fetch_uncertainty(h, vel_uncert, baz_uncert)   [nbands][vector_len] each (either may be NULL), zeros beyond
+ *                                   nwin[b]; waits for the pass like nbls_fetch. */
+int nbls_set_uncertainty(nbls_handle* h, const double* eig6);
+int nbls_fetch_uncertainty(nbls_handle* h, double* vel_uncert, double* baz_uncert);
+
 /* Copy the filtered+tapered trace of planned band `band` to host: out[nchans][npts]. */
 int nbls_fetch_filtered(nbls_handle* h, int32_t band, double* out);
 

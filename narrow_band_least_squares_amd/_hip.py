@@ -21,7 +21,7 @@ EXPORTS = [
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
     'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown', 'nbls_filter_segment',
     'nbls_set_filtered', 'nbls_load_result_block', 'nbls_stream_results', 'nbls_result_batches', 'nbls_wait_result_batch',
-    'nbls_comm_set_library',
+    'nbls_comm_set_library', 'nbls_set_uncertainty', 'nbls_fetch_uncertainty',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -85,6 +85,8 @@ def load_library(path=None):
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
     lib.nbls_comm_set_library.argtypes = [C.c_char_p, C.c_int32]
+    lib.nbls_set_uncertainty.argtypes = [vp, dp]
+    lib.nbls_fetch_uncertainty.argtypes = [vp, dp, dp]
     lib.nbls_stream_results.argtypes = [vp, C.c_int32]
     lib.nbls_result_batches.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.nbls_wait_result_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
@@ -154,6 +156,7 @@ class Handle:
         self.nchans = self.npts = self.npairs = 0
         self.nbands = self.vector_len = 0
         self._keep = []
+        self.profiling = False
 
     def close(self):
         if getattr(self, '_h', None):
@@ -339,6 +342,18 @@ class Handle:
         mask = buf.view(np.uint8)[moff:moff + cells * mb].reshape(B, VL, mb)
         return dict(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], mask=mask)
 
+    def set_uncertainty(self, eig6=None):
+        """``eig6`` = (lambda_0, lambda_1, R00, R01, R10, R11) of the co-array (``planner.uncertainty_frame``): the
+        next plans also compute ltsva's confidence intervals on the GPU; None switches that off."""
+        e = None if eig6 is None else _f64(eig6)
+        self._chk(self.lib.nbls_set_uncertainty(self._h, _dptr(e)))
+
+    def fetch_uncertainty(self):
+        """-> (vel_uncert, baz_uncert), each (nbands, vector_len)."""
+        out = np.empty((2, self.nbands, self.vector_len))
+        self._chk(self.lib.nbls_fetch_uncertainty(self._h, _dptr(out[0]), _dptr(out[1])))
+        return out[0], out[1]
+
     def stream_results(self, on=True):
         """The next passes deliver their rows batch by batch into a pinned host mirror of the result block
         (``nbls_stream_results``); see ``result_batches`` / ``wait_result_batch``."""
@@ -391,6 +406,7 @@ class Handle:
 
     def set_profiling(self, on=True):
         self._chk(self.lib.nbls_set_profiling(self._h, int(bool(on))))
+        self.profiling = bool(on)
 
     def timings(self):
         t = Timings()

@@ -272,7 +272,7 @@ void nbls_destroy(nbls_handle* h) {
     void* bufs[] = {h->d_trace, h->d_xij, h->d_pair, h->d_xpinv, h->d_sos, h->d_M, h->d_tl, h->d_tr,
                     h->d_W, h->d_inc, h->d_nwin, h->d_unit_off, h->d_unit_band, h->d_unit_win, h->d_filt, h->d_cstate, h->d_cstate2, h->d_tstate,
                     h->d_lag, h->d_cmax, h->d_res /* vel, baz, mdccm, sigma_tau, mask */, h->d_z, h->d_wts,
-                    h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_xss, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
+                    h->d_unc, h->d_starts, h->d_rew, h->d_xs, h->d_xc, h->d_xss, h->d_qbuf, h->d_qmeta, h->d_cand, h->d_fw, h->d_gend, h->d_gin, h->d_win_off, h->d_stamps, h->d_seg_state};
     {
         std::unordered_set<const void*> in_arena;       // members that point into d_parena
         for (const void* m : h->arena_owned) in_arena.insert(*(void* const*)m);
@@ -629,6 +629,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if ((rc = ensure(h, &h->d_cmax, &h->cap_cmax, cells * P * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_z, &h->cap_z, 2 * cells * sizeof(double)))) return rc;
     if ((rc = ensure(h, &h->d_wts, &h->cap_wts, cells * P))) return rc;
+    if (h->want_unc && (rc = ensure(h, &h->d_unc, &h->cap_unc, 2 * cells * sizeof(double)))) return rc;
     h->d_vel = (double*)h->d_res;
     h->d_baz = h->d_vel + cells;
     h->d_mdccm = h->d_baz + cells;
@@ -930,6 +931,39 @@ int nbls_fetch(nbls_handle* h, double* vel, double* baz, double* mdccm, double* 
     if (z) {
         if (ran_s) { HIPCHK(h, copy_sync(h, z, h->d_z, 2 * cells * sizeof(double), hipMemcpyDeviceToHost)); zero_uncomputed(z, 2 * sizeof(double)); }
         else memset(z, 0, 2 * cells * sizeof(double));
+    }
+    return NBLS_OK;
+}
+
+int nbls_set_uncertainty(nbls_handle* h, const double* eig6) {
+    if (!h) return NBLS_ERR_ARG;
+    h->want_unc = eig6 != nullptr;
+    if (eig6) {
+        if (!(eig6[0] > 0.0) || !(eig6[1] > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_uncertainty: the eigenvalues of X^T X must be positive");
+        for (int i = 0; i < 6; ++i) h->unc_par[i] = eig6[i];
+    }
+    h->planned = false;                      // (the next plan sizes the output buffer)
+    return NBLS_OK;
+}
+
+int nbls_fetch_uncertainty(nbls_handle* h, double* vel_uncert, double* baz_uncert) {
+    if (!h) return NBLS_ERR_ARG;
+    if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_fetch_uncertainty: no plan");
+    if (!h->want_unc || !h->d_unc) return fail(h, NBLS_ERR_STATE, "nbls_fetch_uncertainty: nbls_set_uncertainty before nbls_plan");
+    { const int rc = finish_pass(h); if (rc) return rc; }
+    const size_t cells = (size_t)h->nbands * h->vector_len;
+    double* outs[2] = {vel_uncert, baz_uncert};
+    for (int g = 0; g < 2; ++g) {
+        if (!outs[g]) continue;
+        if (!(h->last_stage_mask & 4)) { memset(outs[g], 0, cells * sizeof(double)); continue; }
+        HIPCHK(h, copy_sync(h, outs[g], h->d_unc + g * cells, cells * sizeof(double), hipMemcpyDeviceToHost));
+        // rows of windows this plan did not compute are zeros, like the grids
+        for (int b = 0; b < h->nbands; ++b) {
+            const int64_t first = (int)h->woff.size() == h->nbands ? h->woff[b] : 0, n = h->nwin[b];
+            double* band = outs[g] + (size_t)b * h->vector_len;
+            for (int64_t w = 0; w < first; ++w) band[w] = 0.0;
+            for (int64_t w = first + n; w < h->vector_len; ++w) band[w] = 0.0;
+        }
     }
     return NBLS_OK;
 }

@@ -148,6 +148,11 @@ struct nbls_handle {
     double* d_mdccm = nullptr;
     double* d_sig = nullptr;
     uint8_t* d_mask = nullptr;     // [B][VL][MB] (view into d_res)
+    // confidence intervals of the slowness estimate (nbls_set_uncertainty): computed behind the solve when wanted
+    bool want_unc = false;
+    double unc_par[6] = {0, 0, 0, 0, 0, 0};   // eigenvalues of X^T X, rotation into the eigen-frame (row major)
+    double* d_unc = nullptr;       // [2][B][VL]: vel_uncert | baz_uncert
+    size_t cap_unc = 0;
     double* d_z = nullptr;         // [B][VL][2]
     uint8_t* d_wts = nullptr;      // [B][VL][P] one byte per pair (kernel-side form; packed into d_mask after the solve)
     size_t cap_filt = 0, cap_cstate = 0, cap_lag = 0, cap_cmax = 0, cap_z = 0, cap_wts = 0;

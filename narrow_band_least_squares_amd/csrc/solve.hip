@@ -96,16 +96,44 @@ __device__ double nanmedian_serial(const double* v, int P) {
     return lo == hi ? vlo : (vlo + vhi) * 0.5;
 }
 
+// nanmedian of a lane's P values kept in LDS as column `lane` of col[k * 64 + lane] (rank counting; the serial form
+// above reads global memory P^2 times per lane — 50-80 us per launch whatever the unit count, the largest stage of a
+// small OLS call).
+__device__ double nanmedian_lds(const double* col, int P) {
+    int m = 0;
+    for (int k = 0; k < P; ++k) { const double vk = col[k * 64]; m += (vk == vk); }
+    if (m == 0) return dnan();
+    const int lo = (m - 1) / 2, hi = m / 2;
+    double vlo = 0.0, vhi = 0.0;
+    for (int k = 0; k < P; ++k) {
+        const double vk = col[k * 64];
+        if (!(vk == vk)) continue;
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const double vj = col[j * 64];
+            rank += (vj < vk) || (vj == vk && j < k);
+        }
+        if (rank == lo) vlo = vk;
+        if (rank == hi) vhi = vk;
+    }
+    return lo == hi ? vlo : (vlo + vhi) * 0.5;
+}
+
 // ------------------------------------------------------------------------------------
-// OLS: one lane per unit.
+// OLS: one lane per unit (64-lane workgroups; MdCCM through LDS when the pairs fit: smem_pairs = P, else 0).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void solve_ols_kernel(SArgs a, int nunits) {
-    const int u = a.u0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= a.u0 + nunits) return;
+__global__ __launch_bounds__(64) void solve_ols_kernel(SArgs a, int nunits, int smem_pairs) {
+    extern __shared__ double ols_col[];                   // [P][64]
+    const int ul = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = ul < nunits;
+    const int u = a.u0 + (live ? ul : 0);
     const int band = a.unit_band[u];
     const int w = u - a.unit_off[band] + a.win_off[band];   // window index inside the band (global)
     const int P = a.npairs;
     const int64_t o = (int64_t)band * a.vector_len + w;
+    if (smem_pairs)
+        for (int k = 0; k < P; ++k) ols_col[k * 64 + threadIdx.x] = a.cmax[o * P + k];
+    if (!live) return;
     const int32_t* lag = a.lag + o * P;
     double z0 = 0.0, z1 = 0.0;
     for (int k = 0; k < P; ++k) {
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(256) void solve_ols_kernel(SArgs a, int nunits) {
     a.sig[o] = sqrt(acc / (double)(P - 2));
     a.z[2 * o] = z0;
     a.z[2 * o + 1] = z1;
-    a.mdccm[o] = nanmedian_serial(a.cmax + o * P, P);
+    a.mdccm[o] = smem_pairs ? nanmedian_lds(ols_col + threadIdx.x, P) : nanmedian_serial(a.cmax + o * P, P);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1184,6 +1212,106 @@ hipError_t launch_fast(nbls_handle* h, const SArgs& a, int nunits, hipStream_t s
 
 #include "solve_bucket.inc"
 
+// ------------------------------------------------------------------------------------
+// Confidence intervals of the slowness estimate — ltsva's 7th / 8th returns (vel_uncert, baz_uncert at
+// narrow_band_least_squares.py:91, example.py:109; Szuberla & Olson 2004 as used by lts_array [R]): the 90 %
+// confidence ellipse of the slowness vector, semi-axes sqrt(chi2_{0.90,2}) sigma_tau / sqrt(lambda_i) along the
+// eigenvectors of X^T X, centred on z.  vel_uncert = half the spread of 1/|s| over the ellipse, baz_uncert = half the
+// angle the ellipse subtends at the origin (NaN when the origin is inside).  One lane per unit, behind the unit's solve:
+//   radial extrema   stationary points of |c + (a cos phi, b sin phi)|^2: the best of NPHI boundary samples (cos / sin
+//                    table shared through LDS), then NEWT clipped Newton steps on f'(phi) = 0
+//   subtended angle  the two tangents from the origin in closed form (unit circle after scaling by the semi-axes)
+// Same operations in the same order as oracle/nbls_oracle.py: confidence_intervals_closed_form (un-fused arithmetic:
+// this file is built with -ffp-contract=off).
+// ------------------------------------------------------------------------------------
+struct UArgs {
+    const double* z;          // [B][VL][2]
+    const double* sig;        // [B][VL]
+    double* vunc;             // [B][VL]
+    double* bunc;             // [B][VL]
+    const int32_t* unit_band;
+    const int32_t* unit_win;
+    int vector_len, u0, nunits;
+    double ev0, ev1;          // eigenvalues of X^T X (ascending, numpy.linalg.eigh)
+    double r00, r01, r10, r11;// rotation into the eigen-frame
+};
+constexpr int UNC_NPHI = 720;
+constexpr int UNC_NEWT = 8;
+constexpr double UNC_CHI2 = 4.605170185988092;          // -2 ln(1 - 0.90) = chi2.ppf(0.90, 2)
+
+__device__ inline double py_mod360(double x) {          // Python's x % 360.0
+    double m = fmod(x, 360.0);
+    if (m != 0.0) { if (m < 0.0) m += 360.0; } else m = 0.0;
+    return m;
+}
+
+__global__ __launch_bounds__(64) void uncertainty_kernel(UArgs a) {
+    __shared__ double cs[UNC_NPHI], sn[UNC_NPHI];
+    const double step = 6.283185307179586 / (double)UNC_NPHI;
+    for (int k = threadIdx.x; k < UNC_NPHI; k += 64) {
+        double s_, c_;
+        sincos((double)k * step, &s_, &c_);
+        sn[k] = s_; cs[k] = c_;
+    }
+    __syncthreads();
+    const int ul = blockIdx.x * 64 + threadIdx.x;
+    if (ul >= a.nunits) return;
+    const int u = a.u0 + ul;
+    const int64_t o = (int64_t)a.unit_band[u] * a.vector_len + a.unit_win[u];
+    const double z0 = a.z[2 * o], z1 = a.z[2 * o + 1], sg = a.sig[o];
+    const double nan_ = dnan();
+    const double q = sqrt(UNC_CHI2);
+    const double sa = q * sg / sqrt(a.ev0), sb = q * sg / sqrt(a.ev1);
+    const double x0 = z0 * a.r00 + z1 * a.r01, y0 = z0 * a.r10 + z1 * a.r11;
+    const bool ok = isfinite(sa) && isfinite(sb) && isfinite(x0) && isfinite(y0);
+    if (!ok) { a.vunc[o] = nan_; a.bunc[o] = nan_; return; }
+    if (sa == 0.0 && sb == 0.0) { a.vunc[o] = 0.0; a.bunc[o] = 0.0; return; }     // exact fit: a point, no spread
+    // ---- radial extrema ----
+    int kmin = 0, kmax = 0;
+    double fmin_ = 0.0, fmax_ = 0.0;
+    for (int k = 0; k < UNC_NPHI; ++k) {
+        const double cx = x0 + sa * cs[k], cy = y0 + sb * sn[k];
+        double f = cx * cx + cy * cy;
+        if (!isfinite(f)) f = 0.0;
+        if (k == 0 || f < fmin_) { fmin_ = f; kmin = k; }
+        if (k == 0 || f > fmax_) { fmax_ = f; kmax = k; }
+    }
+    double rext[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        double p = (double)(e == 0 ? kmin : kmax) * step;
+        for (int it = 0; it < UNC_NEWT; ++it) {
+            double s_, c_;
+            sincos(p, &s_, &c_);
+            const double g = -sa * s_ * (x0 + sa * c_) + sb * c_ * (y0 + sb * s_);                               // f'/2
+            const double c2 = c_ * c_ - s_ * s_;
+            const double hh = -sa * c_ * x0 - sa * sa * c2 - sb * s_ * y0 + sb * sb * c2;                        // f''/2
+            double st = fabs(hh) > 0.0 ? g / hh : 0.0;
+            st = st < -0.05 ? -0.05 : (st > 0.05 ? 0.05 : st);
+            p = p - st;
+        }
+        double s_, c_;
+        sincos(p, &s_, &c_);
+        rext[e] = hypot(x0 + sa * c_, y0 + sb * s_);
+    }
+    a.vunc[o] = 0.5 * fabs(1.0 / rext[0] - 1.0 / rext[1]);
+    // ---- subtended angle ----
+    const double pz = sa > 0.0 ? x0 / sa : __builtin_inf(), qz = sb > 0.0 ? y0 / sb : __builtin_inf();
+    const double d2 = pz * pz + qz * qz;
+    if (!(d2 > 1.0)) { a.bunc[o] = nan_; return; }                                  // origin inside: direction undetermined
+    const double root = sqrt(d2 - 1.0) / d2, kk = 1.0 - 1.0 / d2;
+    const double t1x = sa * (pz * kk - root * qz), t1y = sb * (qz * kk + root * pz);
+    const double t2x = sa * (pz * kk + root * qz), t2y = sb * (qz * kk - root * pz);
+    // back to the east / north frame: t @ R
+    const double e1x = t1x * a.r00 + t1y * a.r10, e1y = t1x * a.r01 + t1y * a.r11;
+    const double e2x = t2x * a.r00 + t2y * a.r10, e2y = t2x * a.r01 + t2y * a.r11;
+    const double th1 = py_mod360(atan2(e1y, e1x) * (180.0 / 3.141592653589793) - 360.0);
+    const double th2 = py_mod360(atan2(e2y, e2x) * (180.0 / 3.141592653589793) - 360.0);
+    double dth = fabs(th1 - th2);
+    if (dth > 180.0) dth = fabs(dth - 360.0);
+    a.bunc[o] = 0.5 * dth;
+}
+
 size_t lts_lds_bytes(int P, int S, bool absr) {
     size_t b = (size_t)(8 * P + 3 * S + 3 * NBLS_MAX_CAND) * sizeof(double);
     b += (size_t)(S + P + NBLS_MAX_CAND + 4) * sizeof(int);
@@ -1228,6 +1356,17 @@ hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipS
 hipError_t nbls_launch_solve_range(nbls_handle* h, int64_t u0, int64_t nu, hipStream_t st) {
     hipError_t e = solve_range_impl(h, u0, nu, st);
     if (e != hipSuccess) return e;
+    if (h->want_unc && h->d_unc && nu > 0) {
+        UArgs a{};
+        const size_t cells = (size_t)h->nbands * h->vector_len;
+        a.z = h->d_z; a.sig = h->d_sig; a.vunc = h->d_unc; a.bunc = h->d_unc + cells;
+        a.unit_band = h->d_unit_band; a.unit_win = h->d_unit_win;
+        a.vector_len = h->vector_len; a.u0 = (int)u0; a.nunits = (int)nu;
+        a.ev0 = h->unc_par[0]; a.ev1 = h->unc_par[1];
+        a.r00 = h->unc_par[2]; a.r01 = h->unc_par[3]; a.r10 = h->unc_par[4]; a.r11 = h->unc_par[5];
+        hipLaunchKernelGGL(uncertainty_kernel, dim3((unsigned)((nu + 63) / 64)), dim3(64), 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     return nbls_launch_pack_weights(h, u0, nu, st);
 }
 
@@ -1254,7 +1393,8 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.wts = h->d_wts;
     const int nunits = (int)nu;
     if (!h->lts) {
-        hipLaunchKernelGGL(solve_ols_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st, a, nunits);
+        const int sp = h->npairs <= 64 ? h->npairs : 0;          // the lanes' MdCCM columns in LDS (<= 32 KB)
+        hipLaunchKernelGGL(solve_ols_kernel, dim3((nunits + 63) / 64), dim3(64), (size_t)sp * 64 * sizeof(double), st, a, nunits, sp);
         return hipGetLastError();
     }
     a.xs = h->d_xs;

@@ -333,7 +333,7 @@ def upload_trace(h, data, fs):
 
 
 def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0, trace_from=None,
-           trace_ready=False, after=None, before_execute=None, stream=False):
+           trace_ready=False, after=None, before_execute=None, stream=False, uncert=False):
     """Upload (optional), plan and start the pass for the band subset ``bands`` (indices into the Prep;
     None = all) on handle ``h``.  Returns as soon as the kernels are queued.  ``trace_from``: another handle of
     the same GPU that already holds this trace (device-to-device copy instead of a second upload).
@@ -356,6 +356,7 @@ def launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl
         first = (nw * k) // n
         h.set_window_ranges(first, (nw * (k + 1)) // n - first)
     h.reserve_results(reserve_bytes)
+    h.set_uncertainty(planner.uncertainty_frame(prep.xij) if uncert else None)     # (ltsva's confidence intervals, on request)
     try:
         h.plan(sos, prep.zero_phase, prep.tl, prep.tr, prep.W[idx], prep.inc[idx], prep.vector_len, lts=prep.lts,
                xcorr_impl=xcorr_impl)
@@ -387,7 +388,8 @@ def split_block(block, nbands, vector_len, mask_bytes):
 def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filter_type=None,
             filter_order=None, filter_ripple=None, vector_len=None, device=None, xcorr_impl=0,
             want_lag=False, want_cmax=False, want_z=False, prefiltered=False, handle=None,
-            upload=True, window_slice=None, host_overlap=None, group_done=None, groups=None, units_done=None):
+            upload=True, window_slice=None, host_overlap=None, group_done=None, groups=None, units_done=None,
+            want_uncert=False):
     """Run the hot path for a list of bands on one GPU.
 
     window_slice=(k, n): process only the k-th of n contiguous window slices of every band (window
@@ -396,6 +398,8 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     data (N, npts) raw traces — a 2-D array or a list of N rows (uploaded from where they lie);
     band_edges [(fmin, fmax), ...]; winlens [seconds per band].
     prefiltered=True: ``data`` is already filtered/tapered (``ltsva`` entry), one band.
+    want_uncert=True: also ``res.vel_uncert`` / ``res.baz_uncert`` (nbands, vector_len), the confidence intervals of
+    the slowness estimate, computed on the GPU behind each unit's solve (``nbls_set_uncertainty``).
 
     Host/GPU overlap: the bands are cut into ``groups`` contiguous groups (``pipeline_groups``), each an
     asynchronous pass on its own handle of the same GPU, queued as soon as its filters are designed.
@@ -493,9 +497,11 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         lag = np.zeros((nb, vector_len, P), dtype=np.int32) if want_lag else None
         cmax = np.zeros((nb, vector_len, P)) if want_cmax else None
         z = np.zeros((nb, vector_len, 2)) if want_z else None
+        unc = np.zeros((2, nb, vector_len)) if want_uncert else None
         res = BandBatch(vel=grids[0], baz=grids[1], mdccm=grids[2], sigma_tau=grids[3], nwin=nwin.astype(int), t=None,
                         mask=mask, lag=lag, cmax=cmax, z=z, sos=[], W=W, inc=inc, pair_idx=None, xij=None,
-                        nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs)
+                        nchans=nchans, alpha=alpha, handle=None, lts=alpha < 1.0, fs=fs,
+                        vel_uncert=None if unc is None else unc[0], baz_uncert=None if unc is None else unc[1])
 
         deferred = []                                 # rounds collected before host_overlap has run (sequential rounds)
 
@@ -525,6 +531,8 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                     if bd > done_band[0]:
                         group_done(res, done_band[0], bd)
                         done_band[0] = bd
+            if getattr(h, 'profiling', False):
+                h.sync()                               # (turns the pass's events into ``timings()``)
 
         def collect(h, b0, b1, notify=True):
             if streamed:
@@ -538,6 +546,8 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                 for name, arr in (('lag', lag), ('cmax', cmax), ('z', z)):
                     if arr is not None:
                         arr[b0:b1] = ext[name]
+            if want_uncert:
+                unc[0, b0:b1], unc[1, b0:b1] = h.fetch_uncertainty()
             if not notify:
                 deferred.append((b0, b1))
             elif streamed:
@@ -579,7 +589,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             # itself between the passes and all of them land together at the end (stream priorities alone did the
             # job on some boxes and not on others)
             ordered = launched and not sequential and os.environ.get('NBLS_GROUP_ORDER', '1') != '0'
-            launch(h, data, prep, upload=upload, window_slice=window_slice,
+            launch(h, data, prep, upload=upload, window_slice=window_slice, uncert=want_uncert,
                    xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
                    trace_ready=early, after=launched[-1][0] if ordered else None,
                    before_execute=upload_done if early else None, stream=streamed)

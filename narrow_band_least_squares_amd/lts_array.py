@@ -6,7 +6,6 @@ summarised in SURVEY.md §3.3).
 import numpy as np
 
 from . import engine
-from .uncertainty import confidence_intervals
 from .helpers import get_rij
 
 
@@ -35,7 +34,7 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
             res.keys = engine.time_keys(res.t, res.nwin)
 
     res = engine.process(data, fs, t0, rij, [(None, None)], [window_length], window_overlap, alpha,
-                         prefiltered=True, want_z=True, host_overlap=host_side)
+                         prefiltered=True, host_overlap=host_side, want_uncert=True)
     n = int(res.nwin[0])
     vel = res.vel[0, :n].copy()
     baz = res.baz[0, :n].copy()
@@ -46,5 +45,8 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
         stdict = {}
     else:
         stdict = engine.stdict_from_mask(res.mask, res.nwin, res.pair_idx, nchans, res.keys)
-    conf_int_vel, conf_int_baz = confidence_intervals(res.xij, res.z[0, :n], sigma_tau)
+    # (Szuberla & Olson confidence intervals: per-unit scalar math on the GPU behind the solve, csrc/solve.hip:
+    #  uncertainty_kernel — no host loop over windows)
+    conf_int_vel = res.vel_uncert[0, :n].copy()
+    conf_int_baz = res.baz_uncert[0, :n].copy()
     return vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz

@@ -433,3 +433,14 @@ def sosfreqz_bands(sos_list, worN, fs):
             h *= num / den
         rows[n] = h
     return w * (fs / (2 * np.pi)), rows
+
+
+def uncertainty_frame(xij):
+    """(lambda_0, lambda_1, R00, R01, R10, R11): eigenvalues (ascending, ``numpy.linalg.eigh``) of X^T X of the co-array
+    and the rotation into its eigen-frame as lts_array builds it [R: source absent] — ``ang = arccos(evecs[0, 0])``,
+    ``R = [[cos, sin], [-sin, cos]]`` — for the confidence intervals the GPU computes behind the solve
+    (``nbls_set_uncertainty``; 7th / 8th returns of ``ltsva``, narrow_band_least_squares.py:91)."""
+    xij = np.asarray(xij, dtype=np.float64)
+    evals, evecs = np.linalg.eigh(xij.T @ xij)
+    ang = np.arccos(np.clip(evecs[0, 0], -1.0, 1.0))
+    return np.array([evals[0], evals[1], np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)])

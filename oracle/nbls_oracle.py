@@ -724,6 +724,73 @@ def confidence_intervals(xij, z, sigma_tau, nphi=400000):
     return civ, cib
 
 
+CHI2_90_2DOF = -2.0 * np.log(1.0 - 0.90)          # chi2.ppf(0.90, 2) = 4.605170185988092
+
+
+def confidence_intervals_closed_form(xij, z, sigma_tau, nsample=720, newton_iters=8):
+    """The same two quantities as ``confidence_intervals`` — which samples the ellipse densely and is the INDEPENDENT
+    check — evaluated the way the GPU's ``uncertainty_kernel`` (csrc/solve.hip) evaluates them, operation for
+    operation, so that the two can be compared to rounding: the radial extrema of the ellipse as stationary points of
+    f(phi) = |c + (a cos phi, b sin phi)|^2 (best of ``nsample`` boundary samples, then ``newton_iters`` clipped Newton
+    steps on f'(phi) = 0), the subtended angle from the two tangents through the origin in closed form (unit circle
+    after scaling by the semi-axes).  [R: lts_array solve()/rthEllipse; Szuberla & Olson 2004.]  z: (2, nits)."""
+    z = np.asarray(z, dtype=np.float64)
+    sig = np.asarray(sigma_tau, dtype=np.float64).reshape(-1)
+    n = len(sig)
+    ci_vel = np.full(n, np.nan)
+    ci_baz = np.full(n, np.nan)
+    if n == 0:
+        return ci_vel, ci_baz
+    evals, evecs = np.linalg.eigh(xij.T @ xij)
+    ang = np.arccos(np.clip(evecs[0, 0], -1.0, 1.0))
+    R = np.array([[np.cos(ang), np.sin(ang)], [-np.sin(ang), np.cos(ang)]])
+    q = np.sqrt(CHI2_90_2DOF)
+    with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+        a = q * sig / np.sqrt(evals[0])
+        b = q * sig / np.sqrt(evals[1])
+        x0 = z[0] * R[0, 0] + z[1] * R[0, 1]            # ellipse centre in the eigen-frame
+        y0 = z[0] * R[1, 0] + z[1] * R[1, 1]
+        ok = np.isfinite(a) & np.isfinite(b) & np.isfinite(x0) & np.isfinite(y0)
+        step = 6.283185307179586 / nsample
+        phi = np.arange(nsample) * step
+        cx = x0[:, None] + a[:, None] * np.cos(phi)[None, :]
+        cy = y0[:, None] + b[:, None] * np.sin(phi)[None, :]
+        f = cx * cx + cy * cy
+        f = np.where(np.isfinite(f), f, 0.0)
+        r_ext = []
+        for pick in (np.argmin, np.argmax):
+            p = pick(f, axis=1) * step
+            for _ in range(newton_iters):
+                s, co = np.sin(p), np.cos(p)
+                g = -a * s * (x0 + a * co) + b * co * (y0 + b * s)                     # f'/2
+                c2 = co * co - s * s
+                h = -a * co * x0 - a * a * c2 - b * s * y0 + b * b * c2                # f''/2
+                st = np.where(np.abs(h) > 0, g / h, 0.0)
+                p = p - np.clip(st, -0.05, 0.05)
+            r_ext.append(np.hypot(x0 + a * np.cos(p), y0 + b * np.sin(p)))
+        rmin, rmax = r_ext
+        ci_vel = 0.5 * np.abs(1.0 / rmin - 1.0 / rmax)
+        pz = np.where(a > 0, x0 / a, np.inf)
+        qz = np.where(b > 0, y0 / b, np.inf)
+        d2 = pz * pz + qz * qz
+        outside = d2 > 1.0
+        root = np.sqrt(np.where(outside, d2 - 1.0, np.nan)) / d2
+        k = 1.0 - 1.0 / d2
+        t1x, t1y = a * (pz * k - root * qz), b * (qz * k + root * pz)
+        t2x, t2y = a * (pz * k + root * qz), b * (qz * k - root * pz)
+        e1x, e1y = t1x * R[0, 0] + t1y * R[1, 0], t1x * R[0, 1] + t1y * R[1, 1]       # back to east / north: t @ R
+        e2x, e2y = t2x * R[0, 0] + t2y * R[1, 0], t2x * R[0, 1] + t2y * R[1, 1]
+        th1 = (np.arctan2(e1y, e1x) * (180.0 / 3.141592653589793) - 360.0) % 360.0
+        th2 = (np.arctan2(e2y, e2x) * (180.0 / 3.141592653589793) - 360.0) % 360.0
+        dth = np.abs(th1 - th2)
+        dth = np.where(dth > 180.0, np.abs(dth - 360.0), dth)
+        ci_baz = np.where(outside, 0.5 * dth, np.nan)
+        zero = ok & (a == 0) & (b == 0)                 # exact fit: a point, no spread
+        ci_vel = np.where(zero, 0.0, ci_vel)
+        ci_baz = np.where(zero, 0.0, ci_baz)
+    return np.where(ok, ci_vel, np.nan), np.where(ok, ci_baz, np.nan)
+
+
 def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
           plot_array_coordinates=False, rij=None, return_internals=False, ci_samples=20000):
     """lts_array.ltsva [R] -> (vel, baz, t, mdccm, stdict, sigma_tau, conf_int_vel, conf_int_baz).
@@ -764,7 +831,12 @@ def ltsva(st, lat_list, lon_list, window_length, window_overlap, alpha=1.0,
         z, weights, sigma_tau = lts_post_process(tau, xij, zraw, alpha)
         vel, baz = vel_baz(z)
         stdict = stdict_from_weights(weights, idx_pair, t, nchans)
-    civ, cib = confidence_intervals(xij, z, sigma_tau, nphi=ci_samples)
+    # ci_samples > 0: the brute-force evaluation (dense boundary sampling); 0: the stationary-point / tangent form the
+    # GPU kernel follows (compared with each other in tests/test_host.py)
+    if ci_samples:
+        civ, cib = confidence_intervals(xij, z, sigma_tau, nphi=ci_samples)
+    else:
+        civ, cib = confidence_intervals_closed_form(xij, z, sigma_tau)
     out = (vel, baz, t, mdccm, stdict, sigma_tau, civ, cib)
     if return_internals:
         return out, dict(tau=tau, cmax=cmax, z=z, weights=weights, W=W, inc=inc,

@@ -120,9 +120,17 @@ def _compare_ltsva(oracle, c, stf_o, winlen, alpha):
     data = np.array([tr.data for tr in stf_o])
     res = engine.process(data, c['fs'], oracle.start_datenum(stf_o[0].stats.starttime), c['rij'],
                          [(None, None)], [winlen], 0.5, alpha, prefiltered=True, want_lag=True,
-                         want_cmax=True, want_z=True)
+                         want_cmax=True, want_z=True, want_uncert=True)
     n = int(res.nwin[0])
     assert n == len(out_o[0])
+    # confidence intervals (uncertainty_kernel, behind the solve): the same closed form evaluated by the oracle on the
+    # SAME z and sigma_tau -> rounding only; end to end (the oracle's own z / sigma_tau, its dense-sampling evaluation) below
+    cv_x, cb_x = oracle.confidence_intervals_closed_form(internals['xij'], res.z[0, :n].T, res.sigma_tau[0, :n])
+    np.testing.assert_allclose(res.vel_uncert[0, :n], cv_x, rtol=1e-9, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(res.baz_uncert[0, :n], cb_x, rtol=1e-9, atol=1e-10, equal_nan=True)
+    assert not np.any(res.vel_uncert[0, n:]) and not np.any(res.baz_uncert[0, n:])
+    np.testing.assert_allclose(res.vel_uncert[0, :n], out_o[6], rtol=1e-5, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(res.baz_uncert[0, :n], out_o[7], rtol=1e-5, atol=1e-7, equal_nan=True)
     lag_o = np.rint(internals['tau'].T * c['fs']).astype(int)
     np.testing.assert_array_equal(res.lag[0, :n], lag_o)
     np.testing.assert_allclose(res.cmax[0, :n], internals['cmax'].T, rtol=1e-12, atol=1e-14)

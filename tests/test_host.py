@@ -162,9 +162,11 @@ def test_band_sharded_path_world_size_2_gloo(gold, mode):
 
 
 def test_confidence_intervals_against_brute_force(oracle):
-    """Product (closed-form tangents + Newton-refined radial extrema) vs the oracle's dense sampling of
-    the Szuberla & Olson confidence ellipse; origin-inside and exact-fit cases included."""
-    from narrow_band_least_squares_amd.uncertainty import confidence_intervals
+    """The stationary-point / tangent form of the confidence intervals — what the GPU's uncertainty_kernel computes,
+    restated in the oracle as confidence_intervals_closed_form — against the INDEPENDENT evaluation: the oracle's dense
+    sampling of the Szuberla & Olson confidence ellipse; origin-inside and exact-fit cases included.  (The GPU kernel
+    itself is compared with the closed form at 1e-9 in tests/test_gpu_parity.py: test_ltsva_parity.)"""
+    confidence_intervals = oracle.confidence_intervals_closed_form
     rng = np.random.default_rng(12)
     xij, _ = oracle.co_array(rng.uniform(-1, 1, size=(2, 7)))
     z = rng.standard_normal((2, 12)) * 2.5
@@ -172,7 +174,7 @@ def test_confidence_intervals_against_brute_force(oracle):
     sig[3] = 0.0                      # exact fit
     sig[5] = 50.0                     # huge ellipse: the origin is inside
     z[:, 7] = np.nan
-    civ, cib = confidence_intervals(xij, z.T, sig)
+    civ, cib = confidence_intervals(xij, z, sig)
     ov, ob = oracle.confidence_intervals(xij, z, sig)
     np.testing.assert_allclose(civ, ov, rtol=1e-7, atol=1e-12, equal_nan=True)
     np.testing.assert_allclose(cib, ob, rtol=1e-7, atol=1e-9, equal_nan=True)
@@ -180,9 +182,13 @@ def test_confidence_intervals_against_brute_force(oracle):
     assert np.isnan(civ[7]) and np.isnan(cib[7])
     # a tight ellipse far from the origin: half-widths follow the small-angle formulas
     zz = np.array([[3.0], [0.0]])
-    ev = np.linalg.eigvalsh(xij.T @ xij)
-    cv, cb = confidence_intervals(xij, zz.T, np.array([1e-6]))
+    cv, cb = confidence_intervals(xij, zz, np.array([1e-6]))
     assert cb[0] < 1e-3 and cv[0] < 1e-6
+    # the frame handed to the GPU (planner.uncertainty_frame) is the oracle's
+    ev, evec = np.linalg.eigh(xij.T @ xij)
+    fr = planner.uncertainty_frame(xij)
+    ang = np.arccos(evec[0, 0])
+    np.testing.assert_array_equal(fr, [ev[0], ev[1], np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)])
 
 
 def test_stdict_packing_matches_oracle(oracle):

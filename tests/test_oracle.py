@@ -212,6 +212,10 @@ def test_oracle_band_loop_equals_reference_loop(oracle, name, capsys):
         assert set(out[4].keys()) == set(sd.keys())
         for k in sd:
             np.testing.assert_array_equal(out[4][k], sd[k])
+        # every LTS fixture exercises the reference's key-prefix code on a NON-EMPTY dictionary, prefixes of several bands
+        # (the overlapping-band fixture used to hold no entry at all)
+        prefixes = {k.split('_')[0] for k in sd if k != 'size'}
+        assert len(sd) > 10 and len(prefixes) >= 2, (name, len(sd), prefixes)
 
 
 def test_oracle_filter_matches_the_references_own_filter_data(oracle):

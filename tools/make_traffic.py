@@ -42,15 +42,18 @@ def main():
                          'launches': int(nf.get(k, nw.get(k, 0)))}
     # passes over all units = total units screened / units per pass: every pass quantises each (unit, channel) once,
     # so use the solve kernels' launch count (one per pass) when present
-    solve = [k for k in per_kernel if k.startswith('solve_')]
-    passes_units = None
-    js = {'tag': tag, 'kernel': dom,
+    # one forward state kernel per device pass (whole calls are ONE streamed pass since round 4)
+    passes = max(1, int(nf.get('filter_state_mfma_kernel', 0) or nf.get('filter_state_kernel', 0) or 1))
+    js = {'tag': tag, 'kernel': dom, 'passes': passes,
+          'xcorr_hbm_bytes_per_pass': (2.0 * fetch.get(dom, 0.0) + write.get(dom, 0.0)) / passes,
+          'all_kernels_hbm_bytes_per_pass': sum(2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in per_kernel) / passes,
           'xcorr_hbm_bytes_per_launch': (2.0 * fetch.get(dom, 0.0) + write.get(dom, 0.0)) / max(1, nf.get(dom, 1)),
           'all_kernels_hbm_bytes_total': sum(2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in per_kernel),
           'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 4 --warmup 1 '
                     '--no-cpu-baseline --no-noise` (with --kernel-trace only); counter values are KiB; FETCH_SIZE doubled per '
-                    'MI355X_MICROARCH.md (gfx950 reports half of a wide 16-B/lane coalesced stream); per-launch mean of the '
-                    'dominant kernel over all its launches; tools/pmc_traffic.sh gives the per-pass sums of every kernel',
+                    'MI355X_MICROARCH.md (gfx950 reports half of a wide 16-B/lane coalesced stream); per PASS = the sum over all '
+                    'launches of the kernel / the number of device passes in the run (one forward filter-state kernel per pass); '
+                    'tools/pmc_traffic.sh gives the per-pass sums of every kernel',
           'per_kernel': per_kernel}
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
     old = {}
@@ -64,7 +67,7 @@ def main():
     old['cfg3'] = js
     json.dump(old, open(path, 'w'), indent=1)
     json.dump(old, open(d + '/traffic.json', 'w'), indent=1)
-    print('traffic per launch (%s): %.1f MB' % (dom, js['xcorr_hbm_bytes_per_launch'] / 1e6))
+    print('traffic per pass (%s): %.1f MB over %d passes' % (dom, js['xcorr_hbm_bytes_per_pass'] / 1e6, passes))
 
 
 if __name__ == '__main__':
