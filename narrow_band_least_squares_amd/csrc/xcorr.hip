@@ -38,10 +38,6 @@ struct XArgs {
     int u0;                   // first unit of this launch (window groups of a plan: nbls_launch_xcorr)
 };
 
-__device__ inline bool better(double v1, int k1, double v2, int k2) {
-    return (v1 > v2) || (v1 == v2 && k1 < k2);
-}
-
 // ------------------------------------------------------------------------------------
 // v1: plain VALU kernel.  One workgroup per (unit, pair); both channel windows staged in
 // LDS; thread t owns lags t, t+256, ...; consecutive lanes read consecutive LDS words
@@ -87,6 +83,7 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
 
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
+    const double nrm_ab = sqrt(ssa * ssb);               // maxima are compared by quotient, like np.argmax(cij / norm)
     const int nl = 2 * W - 1;
     for (int kk = tid; kk < nl; kk += 256) {
         const int d = kk - (W - 1);
@@ -102,18 +99,18 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
         }
         for (; n < nhi; ++n) c0 = __builtin_fma(sa[n + d], sb[n], c0);
         const double c = (c0 + c1) + (c2 + c3);
-        if (better(c, kk, best, bestk)) { best = c; bestk = kk; }
+        if (nbls_wave::better_q(c, kk, best, bestk, nrm_ab)) { best = c; bestk = kk; }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_down(best, off, 64);
         const int ok = __shfl_down(bestk, off, 64);
-        if (better(ov, ok, best, bestk)) { best = ov; bestk = ok; }
+        if (nbls_wave::better_q(ov, ok, best, bestk, nrm_ab)) { best = ov; bestk = ok; }
     }
     if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_k[tid >> 6] = bestk; }
     __syncthreads();
     if (tid < 64) {
         for (int i = 1; i < 4; ++i)
-            if (better(red_v[i], red_k[i], best, bestk)) { best = red_v[i]; bestk = red_k[i]; }
+            if (nbls_wave::better_q(red_v[i], red_k[i], best, bestk, nrm_ab)) { best = red_v[i]; bestk = red_k[i]; }
         if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {      // NaN / Inf samples: NumPy's semantics
             bestk = nbls_wave::nonfinite_argmax(sa, sb, W, tid);
             best = __builtin_nan("");
@@ -196,6 +193,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
     const double* pb = sm + (size_t)j * CS + PF + kq - 16 * s;    // + n'
     double bestv = -__builtin_inf();
     int bestk = 0x7fffffff;
+    const double nrm_wj = sqrt(wv < j ? nrm[wv] * nrm[j] : nrm[j] * nrm[wv]);    // (product in pair order ci < cj, as in the final division)
     const int step = 16 * S;
     for (int D0 = 0; D0 < W; D0 += step) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -216,7 +214,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
                 const int d = D0 + 16 * s + kq + 4 * reg;
                 if (d < W) {
                     const int kk = (wv < j) ? (W - 1 + d) : (W - 1 - d);
-                    if (better(acc[reg], kk, bestv, bestk)) { bestv = acc[reg]; bestk = kk; }
+                    if (nbls_wave::better_q(acc[reg], kk, bestv, bestk, nrm_wj)) { bestv = acc[reg]; bestk = kk; }
                 }
             }
         }
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
     for (int off = 16; off <= 32; off <<= 1) {
         const double ov = __shfl_xor(bestv, off, 64);
         const int ok = __shfl_xor(bestk, off, 64);
-        if (better(ov, ok, bestv, bestk)) { bestv = ov; bestk = ok; }
+        if (nbls_wave::better_q(ov, ok, bestv, bestk, nrm_wj)) { bestv = ov; bestk = ok; }
     }
     if (lane < 16) { cbv[wv * 16 + lane] = bestv; cbk[wv * 16 + lane] = bestk; }
     __syncthreads();
@@ -232,11 +230,12 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
         const int ci = a.pair[2 * tid], cj = a.pair[2 * tid + 1];     // ci < cj
         double bv = -__builtin_inf();
         int bk = 0x7fffffff;
+        const double nrm_p = sqrt(nrm[ci] * nrm[cj]);
         for (int ss = 0; ss < S; ++ss) {
             const int c1 = (cj - 1) + (N - 1) * ss;     // wave ci, partner cj
-            if (better(cbv[ci * 16 + c1], cbk[ci * 16 + c1], bv, bk)) { bv = cbv[ci * 16 + c1]; bk = cbk[ci * 16 + c1]; }
+            if (nbls_wave::better_q(cbv[ci * 16 + c1], cbk[ci * 16 + c1], bv, bk, nrm_p)) { bv = cbv[ci * 16 + c1]; bk = cbk[ci * 16 + c1]; }
             const int c2 = ci + (N - 1) * ss;           // wave cj, partner ci
-            if (better(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
+            if (nbls_wave::better_q(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk, nrm_p)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
         }
         if (!nbls_wave::finite_f64(nrm[ci]) || !nbls_wave::finite_f64(nrm[cj])) {
             // NaN / Inf samples: NumPy's semantics (see wave_ops.h nonfinite_argmax), scanned by this one thread
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
         }
         const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + tid;
         a.lag[o] = (W - 1) - bk;
-        a.cmax[o] = bv / sqrt(nrm[ci] * nrm[cj]);
+        a.cmax[o] = bv / nrm_p;
     }
 }
 

@@ -911,10 +911,6 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
 }
 
 // ------------------------------------------------------------------ 3. verify (FP64)
-__device__ inline bool better(double v1, int k1, double v2, int k2) {
-    return (v1 > v2) || (v1 == v2 && k1 < k2);
-}
-
 // Exact FP64 correlation values of up to four candidate indices at once (one wave; lanes stride the
 // samples, the partner sample is loaded once for the four).  Unused entries carry kk = -1.
 // NQ candidate lags of one pair at once: sum_n xa[n + d_q] * xb[n].  Out-of-window samples are read
@@ -1016,6 +1012,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
                                    double ssa, double ssb, int lane, double* best_out, int* bestk_out, double* scr = nullptr) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
+    const double nrm = sqrt(ssa * ssb);                  // (the maxima are compared as the reference compares them: by quotient)
     if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {
         // NaN / Inf samples in a window (gappy trace): the screening saw them as zeros; the answer is NumPy's
         bestk = nbls_wave::nonfinite_argmax(xa, xb, W, lane);
@@ -1065,7 +1062,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
                 else { const int kk1[4] = {k0, -1, -1, -1}; wave_dot<1>(xa, xb, zero, W, kk1, lane, v); }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (q < len && better(v[q], k0 + q, best, bestk)) { best = v[q]; bestk = k0 + q; }
+                    if (q < len && nbls_wave::better_q(v[q], k0 + q, best, bestk, nrm)) { best = v[q]; bestk = k0 + q; }
             };
             for (int p = 0; p < nlist; ) {
                 const int k0 = __builtin_amdgcn_readlane(srt, p);
@@ -1097,7 +1094,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
             else wave_dot<1>(xa, xb, zero, W, kk, lane, v);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (kk[q] >= 0 && better(v[q], kk[q], best, bestk)) { best = v[q]; bestk = kk[q]; }
+                if (kk[q] >= 0 && nbls_wave::better_q(v[q], kk[q], best, bestk, nrm)) { best = v[q]; bestk = kk[q]; }
         }
     }
     *best_out = best;
