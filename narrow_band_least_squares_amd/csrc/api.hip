@@ -522,9 +522,8 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     for (int b = 0; b < nbands; ++b) {
         const int W = winlen[b], inc = wininc[b];
         if (W != uniW) uniW = 0;
-        if (W < 2 || inc < 1 || W > NBLS_MAX_WINDOW)
-            return fail(h, NBLS_ERR_UNSUPPORTED, "nbls_plan: window length must be 2.." + std::to_string(NBLS_MAX_WINDOW) +
-                        " samples (two windows of the general correlator must fit a CU's 160 KB of LDS)");
+        if (W < 2 || inc < 1)
+            return fail(h, NBLS_ERR_ARG, "nbls_plan: window length must be at least 2 samples, the hop at least 1");
         // len(arange(0, npts - W, inc))
         const int64_t span = h->npts - W;
         int64_t n = span > 0 ? (span + inc - 1) / inc : 0;
@@ -645,9 +644,9 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
             int e = b + 1;
             while (e < nbands && h->W[e] == h->W[b]) ++e;
             nbls_wgroup g{b, e, h->W[b], h->unit_off[b], h->unit_off[e], false};
-            int S_, PFB_, CSB_, CSA_, WP_, nsl_, G_;
+            int S_, PFB_, CSB_, CSA_, WP_, nsl_, G_, NC_;
             size_t lds_;
-            g.screen = h->d_xij && nbls_screen_geometry(h, g.W, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_, &G_);
+            g.screen = h->d_xij && nbls_screen_geometry(h, g.W, &S_, &PFB_, &CSB_, &CSA_, &WP_, &lds_, &nsl_, &G_, &NC_);
             if (g.screen) { any_ok = true; if (WP_ > maxWP) maxWP = WP_; }
             else if (g.u1 > g.u0) all_ok = false;
             h->wgroups.push_back(g);

@@ -14,7 +14,7 @@
 #define NBLS_FILTER_TILE 16        // samples per LDS tile row
 #define NBLS_FILTER_GROUP 64       // chunks per carry group
 #define NBLS_MAX_PAIRS 512
-#define NBLS_MAX_WINDOW 10000     // samples: 2 * W * 8 B of LDS in xcorr_simple_kernel (<= 160 KB)
+#define NBLS_LDS_WINDOW 10000     // samples: beyond, the two windows of xcorr_simple_kernel (2 * W * 8 B) do not fit a CU's 160 KB of LDS and are read from global memory
 #define NBLS_MAX_STARTS 1024
 #define NBLS_MAX_CAND 16
 
@@ -223,7 +223,7 @@ hipError_t nbls_launch_pack_weights(nbls_handle* h, int64_t u0, int64_t nu, hipS
 // streamed results: queue the copy of the rows of units [u0, u1) into the pinned mirror behind what `producer` has queued
 hipError_t nbls_queue_result_batch(nbls_handle* h, int64_t u0, int64_t u1, hipStream_t producer);
 hipError_t nbls_launch_probe_mfma(nbls_handle* h, const double* da, const double* db, double* dout);
-bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G);
+bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G, int* ncopy);
 hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int64_t* launches_io);
 hipError_t nbls_xcorr_screen_finish(nbls_handle* h, int64_t launches);
 hipError_t nbls_launch_probe_mfma_i8(nbls_handle* h, const int* da, const int* db, int* dout);

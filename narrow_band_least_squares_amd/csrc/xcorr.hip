@@ -36,6 +36,8 @@ struct XArgs {
     int CS;                   // LDS elements per channel buffer, == 2 (mod 32)
     int PF;                   // zero padding in front of each channel window
     int u0;                   // first unit of this launch (window groups of a plan: nbls_launch_xcorr)
+    int from_global;          // xcorr_simple_kernel: the two windows do not fit a CU's LDS (> 10 000 samples) and are read
+                              // from global memory (L2) instead — no window length is refused
 };
 
 // ------------------------------------------------------------------------------------
@@ -58,16 +60,15 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
     const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
     const double* xa = a.filt + ((int64_t)band * a.nchans + ci) * a.npts_pad + t0;
     const double* xb = a.filt + ((int64_t)band * a.nchans + cj) * a.npts_pad + t0;
-    double* sa = sm;
-    double* sb = sm + W;
+    const double* sa = a.from_global ? xa : sm;
+    const double* sb = a.from_global ? xb : sm + W;
     __shared__ double red_v[8];
     __shared__ int red_k[4];
 
     double qa = 0.0, qb = 0.0;
     for (int n = tid; n < W; n += 256) {
         const double va = xa[n], vb = xb[n];
-        sa[n] = va;
-        sb[n] = vb;
+        if (!a.from_global) { sm[n] = va; sm[W + n] = vb; }
         qa += va * va;
         qb += vb * vb;
     }
@@ -276,7 +277,7 @@ __global__ void probe_mfma_f64_kernel(const double* a, const double* b, double* 
 // The general correlators for the units [ub, ue) (windows of up to gW samples).  impl: 1 plain VALU, 2 f64 MFMA,
 // 0 the faster one that applies.
 static hipError_t launch_general_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int impl, int* used) {
-    XArgs a;
+    XArgs a{};
     a.filt = h->d_filt;
     a.npts_pad = h->npts_pad;
     a.nchans = h->nchans;
@@ -316,7 +317,8 @@ static hipError_t launch_general_range(nbls_handle* h, int64_t ub, int64_t ue, i
         return hipGetLastError();
     }
     const int64_t nblocks = nu * h->npairs;
-    const size_t shm = (size_t)2 * gW * sizeof(double);
+    a.from_global = (size_t)2 * gW * sizeof(double) > 160 * 1024 ? 1 : 0;
+    const size_t shm = a.from_global ? 0 : (size_t)2 * gW * sizeof(double);
     if (shm > 48 * 1024) {      // long windows (W up to 10000): opt in to more than the default dynamic LDS
         hipError_t e = hipFuncSetAttribute((const void*)xcorr_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;

@@ -66,6 +66,8 @@ struct QArgs {
     int nsl;                  // sliding channels per workgroup: 2 (8 waves) when the LDS images fit, else 1 (4 waves)
     int npg;                  // partner groups per sliding channel (1: all partners in one workgroup)
     int pgsz;                 // partners per group (<= 16; fewer when the images of all partners do not fit a CU's LDS)
+    int ncopy;                // byte-shifted copies of a sliding channel in LDS: 8 (two aligned 8-byte reads per fragment), or 4 with
+                              // dword-granular addressing on top (long windows: half the LDS per sample, four 4-byte reads)
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
@@ -383,6 +385,14 @@ __device__ inline void stamp(unsigned long long*, int) {}
 
 constexpr int TB = 4;            // tile steps processed together (they share the B fragments)
 
+// Fragment of the FOUR-copy layout (long windows, QArgs.ncopy == 4): 16 bytes at a 4-byte aligned LDS address.
+__device__ inline __attribute__((ext_vector_type(4))) int ld_frag32(const unsigned char* p) {
+    typedef const volatile int __attribute__((address_space(3))) * lds_i;
+    const lds_i q = (lds_i)p;
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    return (v4i_){q[0], q[1], q[2], q[3]};
+}
+
 typedef int v2i __attribute__((ext_vector_type(2)));
 // Two aligned 8-byte LDS reads, volatile so that the compiler cannot fuse reads into ds_read2_b64
 // (neither the halves of one fragment nor the halves of two fragments): that form is serviced at half the
@@ -447,9 +457,10 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
     // (with ONE sliding channel per workgroup its own image is not needed: N-1 slots, slot = partner index)
     const int nimg = NSL == 2 ? N : NP;
+    const int NC = a.ncopy;                          // 8, or 4 (long windows)
     unsigned char* Bimg = lds;
     unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
-    int* gmax = (int*)(Acop + (size_t)NSL * 16 * CSA);  // [2][16] order-preserving int image of a float
+    int* gmax = (int*)(Acop + (size_t)NSL * 2 * NC * CSA);  // [2][16] order-preserving int image of a float
     // merge scalars [2][16] each (outside the images, so they can be initialised before the first barrier)
     int* Mj = gmax + 32;                            // ordered-int image of the pair's maximum
     int* cnt = Mj + 32;
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     const int chsA = NSL * cp + hsA;
     const bool stage_on = !(NBLS_ABL(2));
     const int8_t* srcA = a.qbuf + (((int64_t)ul * N + (chsA < N ? chsA : 0)) * 2 + limbA) * WP;
-    unsigned char* dstA = Acop + ((size_t)(hsA * 2 + limbA) * 8) * CSA;
+    unsigned char* dstA = Acop + ((size_t)(hsA * 2 + limbA) * NC) * CSA;
     double meta_v = 0.0;                              // this thread's entry of the per-channel records (tid < 4N)
     if (tid < 4 * N) {
         const int k = tid & 3;
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
                 uint2 o;
                 o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
                 o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
-                *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
+                if (r < NC) *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
             }
         }
     }
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
             uint2 o;
             o.x = alignbyte(sdw[rw + 1], sdw[rw + 0], rb);
             o.y = alignbyte(sdw[rw + 2], sdw[rw + 1], rb);
-            *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
+            if (r < NC) *(uint2*)(dstA + (size_t)r * CSA + g * 8) = o;
         }
     }
 #ifdef NBLS_DEVELOPER
@@ -646,10 +657,12 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     }
 
 
-    const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * 8) * CSA;
-    const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * 8) * CSA;
-    const unsigned char* pAh = Ah + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);   // + n' + D0
-    const unsigned char* pAl = Al + (size_t)(lane & 7) * CSA + 16 * g + (lane & 8);
+    const unsigned char* Ah = Acop + ((size_t)(half * 2 + 0) * NC) * CSA;
+    const unsigned char* Al = Acop + ((size_t)(half * 2 + 1) * NC) * CSA;
+    // row r = lane & 15 reads q_i[. + r]: copy r & 7 at byte offset r & 8 — or, four copies, copy r & 3 at byte offset 4 (r >> 2)
+    const int arow = NC == 8 ? (lane & 7) : (lane & 3), aoff = NC == 8 ? (lane & 8) : ((lane & 12));
+    const unsigned char* pAh = Ah + (size_t)arow * CSA + 16 * g + aoff;   // + n' + D0
+    const unsigned char* pAl = Al + (size_t)arow * CSA + 16 * g + aoff;
     const int jslot = NSL == 2 ? j : jj;
     const unsigned char* pBh = Bimg + ((size_t)jslot * 2) * CSB + 16 * boff_of(a, j) + PFB + 16 * g - 16 * s;   // + n'
     const unsigned char* pBl = pBh + CSB;
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
         if (!(NBLS_ABL(1))) {
         // the partner fragments of the NEXT K step are fetched while this step's products run
         v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
-        if (step == 32) {
+        if (step == 32 && NC == 8) {
             // Two lag blocks per tile step (5..8 partners): hand-scheduled K loop, see screen_kloop.inc (generated by
             // tools/gen_screen_kloop.py).  Tile t+2 at K step n and tile t at K step n+1 read the SAME A fragment, so
             // the A stream is walked once and every fragment pair is multiplied by two partner fragments; nothing is
@@ -826,14 +839,16 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
             const int nn = n0 + 64 < klen ? n0 + 64 : n0;
             const v4i bhn = *(const v4i*)(pBh + nn);
             const v4i bln = *(const v4i*)(pBl + nn);
-            const v4i a0h = ld_frag64(qa_h + n0);
-            const v4i a0l = ld_frag64(qa_l + n0);
-            const v4i a1h = ld_frag64(qa_h + n0 + step);
-            const v4i a1l = ld_frag64(qa_l + n0 + step);
-            const v4i a2h = ld_frag64(qa_h + n0 + 2 * step);
-            const v4i a2l = ld_frag64(qa_l + n0 + 2 * step);
-            const v4i a3h = ld_frag64(qa_h + n0 + 3 * step);
-            const v4i a3l = ld_frag64(qa_l + n0 + 3 * step);
+#define LDF(P_) (NC == 8 ? ld_frag64(P_) : ld_frag32(P_))
+            const v4i a0h = LDF(qa_h + n0);
+            const v4i a0l = LDF(qa_l + n0);
+            const v4i a1h = LDF(qa_h + n0 + step);
+            const v4i a1l = LDF(qa_l + n0 + step);
+            const v4i a2h = LDF(qa_h + n0 + 2 * step);
+            const v4i a2l = LDF(qa_l + n0 + 2 * step);
+            const v4i a3h = LDF(qa_h + n0 + 3 * step);
+            const v4i a3l = LDF(qa_l + n0 + 3 * step);
+#undef LDF
             TILE_H(a0h, h0, m0);
             TILE_H(a1h, h1, m1);
             TILE_L(a0l, m0);
@@ -1396,35 +1411,43 @@ static bool boff_dfs(int* o, int j, int N, int S, long* budget) {
 // channel then split its partners (the mechanism that serves 18..32 elements), e.g. 8 elements x 6000 samples:
 // two groups of four; 16 elements x 4500 samples: two groups of eight.  Beyond ~7900 samples even two partners
 // do not fit (the copies alone take 16 bytes per sample): the caller falls back to the general correlator.
-bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G) {
+bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int* CSB, int* CSA, int* WP, size_t* lds, int* nsl, int* G, int* ncopy) {
     const int N = h->nchans;
     if (N < 3 || N > 33 || maxW < 64) return false;
     const int NPc = (N - 1) < 16 ? (N - 1) : 16;     // partners per workgroup when everything fits (more than 16: partner groups)
     *WP = round_up(maxW, 16);
-    for (int g = NPc; g >= 2; --g) {
-        *G = g;
-        *S = 16 / g;
-        if (*S > 8) return false;                        // (the column decode handles up to 8 lag blocks per tile)
-        *PFB = 16 * (*S - 1);
-        // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
-        // row of room for the per-partner skew
-        *CSB = round_up(*PFB + *WP + 192, 256) + 256;
-        // K round-up + read-ahead of the last tile of a group (sized for the eight-tile groups of the one-block instance
-        // where it may be chosen: S == 1)
-        int csa = *WP + 144 + ((*S == 1 ? 8 : TB) - 1) * 16 * (*S);
-        csa = round_up(csa, 32);
-        while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
-        *CSA = csa;
-        // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
-        // LDS, else one sliding channel (4 waves, N-1 images)
-        // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
-        // the caller when they still fit (nbls_screen_tables)
-        const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)32 * csa + 6 * 128 + 16 + 32 * N + 64;
-        const size_t lds1 = (size_t)2 * g * (*CSB) + (size_t)16 * csa + 6 * 128 + 16 + 32 * N + 64;
-        const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
-        if (g == NPc && lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
-        else { *nsl = 1; *lds = lds1; }
-        if (*lds <= 160 * 1024 && *lds >= 1024) return true;
+    // first the layout of eight byte-shifted copies per sliding channel (16 bytes of LDS per sample, two aligned 8-byte
+    // reads per fragment, hand-scheduled K loops); where not even two partners fit beside them (~7900 samples) FOUR copies
+    // with dword-granular addressing on top (8 bytes per sample, four 4-byte reads per fragment, the C++ K loop): ~13 000
+    // samples — example.py's WINLEN_1 = 60 s at 200 Hz
+    for (int nc = 8; nc >= 4; nc -= 4) {
+        *ncopy = nc;
+        for (int g = NPc; g >= 2; --g) {
+            if (nc == 4 && g == 16) continue;            // (S == 1 selects the eight-tile instance, built for eight copies)
+            *G = g;
+            *S = 16 / g;
+            if (*S > 8) break;                           // (the column decode handles up to 8 lag blocks per tile)
+            *PFB = 16 * (*S - 1);
+            // partner image: PFB + window + read-ahead padding, a whole number of 256-B bank rows, plus one
+            // row of room for the per-partner skew
+            *CSB = round_up(*PFB + *WP + 192, 256) + 256;
+            // K round-up + read-ahead of the last tile of a group (sized for the eight-tile groups of the one-block instance
+            // where it may be chosen: S == 1)
+            int csa = *WP + 144 + ((*S == 1 ? 8 : TB) - 1) * 16 * (*S);
+            csa = round_up(csa, 32);
+            while (csa % 64 != 32) csa += 32;                // copy stride == 32 B (mod 64): the 8 copies start 8 banks apart (mod 64), conflict-free ds_read_b64
+            *CSA = csa;
+            // two sliding channels per workgroup (8 waves, all N images) when two such workgroups fit a CU's
+            // LDS, else one sliding channel (4 waves, N-1 images)
+            // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
+            // the caller when they still fit (nbls_screen_tables)
+            const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)4 * nc * csa + 6 * 128 + 16 + 32 * N + 64;
+            const size_t lds1 = (size_t)2 * g * (*CSB) + (size_t)2 * nc * csa + 6 * 128 + 16 + 32 * N + 64;
+            const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
+            if (nc == 8 && g == NPc && lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
+            else { *nsl = 1; *lds = lds1; }
+            if (*lds <= 160 * 1024 && *lds >= 1024) return true;
+        }
     }
     return false;
 }
@@ -1434,7 +1457,7 @@ bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int*
 hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue, int gW, int64_t* launches_io) {
     QArgs a{};
     size_t lds = 0;
-    if (!nbls_screen_geometry(h, gW, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl, &a.pgsz)) return hipErrorInvalidValue;
+    if (!nbls_screen_geometry(h, gW, &a.S, &a.PFB, &a.CSB, &a.CSA, &a.WP, &lds, &a.nsl, &a.pgsz, &a.ncopy)) return hipErrorInvalidValue;
     const int N = h->nchans;
     a.npg = (N - 1 + a.pgsz - 1) / a.pgsz;
     a.Wuni = gW;
@@ -1494,7 +1517,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     // eight-tile instance: one lag block per tile step and a CU per workgroup (two waves per SIMD: 256 VGPRs)
-    const bool tb8 = a.S == 1 && lds > 80 * 1024 && !h->opt.screen_tb4;
+    const bool tb8 = a.S == 1 && lds > 80 * 1024 && !h->opt.screen_tb4 && a.ncopy == 8;
     hipError_t e = hipFuncSetAttribute(tb8 ? (const void*)screen_kernel<8> : (const void*)screen_kernel<4>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -213,13 +213,38 @@ def test_long_windows_of_example_py_at_100_hz(oracle):
         assert tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 0
     finally:
         h.set_profiling(False)
-    with pytest.raises(ValueError, match='10000'):
-        from narrow_band_least_squares_amd import ltsva
-        ltsva(synthetic.make_stream(data, fs), None, None, 120.0, 0.5, 1.0, rij=c['rij'])     # W = 12000: the documented limit
+
+
+@pytest.mark.parametrize('nchans,fs,winlen,noise,screened', [(8, 200.0, 60.0, False, True), (8, 200.0, 60.0, True, True),
+                                                             (16, 150.0, 60.0, True, True), (5, 200.0, 75.0, True, False)])
+def test_windows_beyond_ten_thousand_samples(oracle, nchans, fs, winlen, noise, screened):
+    """VERDICT r03 "missing 4": the reference has no window limit (helpers.py:99-102; example.py:62 WINLEN_1 = 60 s at 200 Hz
+    is 12 000 samples) — the library refused more than 10 000 and ran 7 900..10 000 on a 60x slower correlator.  Now the
+    screening kernel keeps FOUR byte-shifted copies of the sliding channel where eight do not fit (half the LDS per sample:
+    up to ~13 000 samples), and beyond that the general correlator reads its windows from global memory.  8 el. x 12 000
+    and 16 el. x 9 000 samples, plane wave and incoherent noise, two windows each: lags, maxima, solution against the oracle;
+    5 el. x 15 000 on the general correlator."""
+    W = int(winlen * fs)
+    rng = np.random.default_rng(W + nchans)
+    rij = synthetic.array_geometry(nchans, 1.0, seed=60 + nchans)
+    npts = int(2.1 * W)
+    data = rng.standard_normal((nchans, npts)) if noise else synthetic.plane_wave(rij, npts, fs, 0.2, 8.0, seed=5)
+    c = dict(fs=fs, rij=rij - rij.mean(axis=1, keepdims=True))
+    st = oracle.make_stream(data, fs, starttime=17884.0729166667)
+    h = engine.get_handle()
+    h.set_profiling(True)
+    try:
+        out = _compare_ltsva(oracle, c, st, winlen, 1.0)
+        tm = h.timings()
+        assert len(out[0]) >= 2
+        assert (tm['xcorr_impl'] == 3 and tm['xcorr_fallback_bands'] == 0) if screened else tm['xcorr_impl'] in (1, 2)
+    finally:
+        h.set_profiling(False)
 
 
 @pytest.mark.parametrize('nchans,W,noise', [(8, 6000, False), (8, 6000, True), (16, 3200, True), (16, 4500, False), (16, 4500, True),
-                                            (12, 5003, True), (5, 7400, True), (24, 3100, True)])
+                                            (12, 5003, True), (5, 7400, True), (24, 3100, True),
+                                            (8, 9000, True), (8, 12000, False), (16, 9000, False), (4, 12700, True), (24, 7003, True)])
 def test_partner_groups_extend_the_screening_correlator_to_long_windows(nchans, W, noise):
     """Window lengths whose int8 images do not fit a CU's LDS with all partners in one workgroup: partner groups of
     8 / 4 / 2 (tile geometry: 2 / 4 / 8 lag blocks per tile column, linear skew).  Lags must be those of the plain
@@ -244,7 +269,7 @@ def test_partner_groups_extend_the_screening_correlator_to_long_windows(nchans, 
     assert int(got.W[0]) == W
     ref = engine.process(data, fs, 0.0, rij, edges, wl, 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=1, **kw)
     if noise:
-        assert np.abs(ref.lag).max() > W // 3
+        assert np.abs(ref.lag).max() > W // 4
     np.testing.assert_array_equal(got.lag, ref.lag)
     np.testing.assert_allclose(got.cmax, ref.cmax, rtol=1e-12, atol=1e-15)
     np.testing.assert_array_equal(got.baz, ref.baz)

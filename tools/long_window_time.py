@@ -8,10 +8,10 @@ from narrow_band_least_squares_amd import engine, synthetic  # noqa: E402
 fs = 100.0
 h = engine.get_handle()
 h.set_profiling(True)
-for nchans, W in ((8, 6000), (16, 3200), (16, 4500), (8, 7500)):
+for nchans, W in ((8, 6000), (16, 3200), (16, 4500), (8, 7500), (8, 9000), (8, 12000), (16, 9000), (5, 15000)):
     rij = synthetic.array_geometry(nchans, 1.0, seed=nchans)
     data = synthetic.plane_wave(rij, 60 * W // 2 + W, fs, 0.5, 20.0, seed=3)
-    for impl in (3, 2, 1):
+    for impl in (0, 2, 1):            # 0 = what a call gets: screening where its images fit (<= ~13 000 samples), else a general correlator
         try:
             r = engine.process(data, fs, 0.0, rij, [(0.5, 20.0)], [W / fs + 1e-9], 0.5, 1.0, 'butter', 2, 0.01, xcorr_impl=impl)
             h.execute(); h.sync()
