@@ -751,8 +751,12 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     h->last_stage_mask = stage_mask;
     // per-batch solves: behind each unit batch of the correlation stage (streamed results: a batch's rows are complete
     // while later batches are still being correlated), on the second stream with option "overlap"
-    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && (h->opt.overlap || h->stream_results);
-    h->solve_on_stream2 = h->fuse_solve && h->opt.overlap && h->stream2;
+    h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && (h->opt.overlap > 0 || h->stream_results);
+    // option "overlap": 1 on, -1 off, 0 auto = on for a streamed pass of several unit batches (measured r04, device
+    // pass: cfg-3 14.7 -> 14.3 ms, cfg-1b 0.95 -> 0.75, cfg-5 174.6 -> 169.0; a single-batch pass only pays the join:
+    // cfg-2 0.93 -> 0.96)
+    const bool several = h->nunits > h->screen_batch || h->wgroups.size() > 1;
+    h->solve_on_stream2 = h->fuse_solve && h->stream2 && (h->opt.overlap > 0 || (h->opt.overlap == 0 && h->stream_results && several));
     // (a caller that did not wait for every batch of the previous pass: its copies read the block this pass clears)
     if (!h->rbatches.empty() && h->cstream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->rev[2 * (h->rbatches.size() - 1) + 1], 0));
     h->rbatches.clear();
@@ -1073,12 +1077,15 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},
         {"screen_tb4", &nbls_options::screen_tb4, false},
+        {"screen_pretest", &nbls_options::screen_pretest, false},
+        {"screen_tb8", &nbls_options::screen_tb8, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
         {"filter_nomfma", &nbls_options::filter_nomfma, false},
         {"ablate", &nbls_options::ablate, true},
         {"screen_stamps", &nbls_options::screen_stamps, true},
+        {"screen_seed", &nbls_options::screen_seed, true},
         {"lts_stamps", &nbls_options::lts_stamps, true},
         {"screen_pad_kb", &nbls_options::screen_pad_kb, true},
         {"lts_pad_kb", &nbls_options::lts_pad_kb, true},

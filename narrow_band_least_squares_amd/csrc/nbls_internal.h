@@ -29,13 +29,16 @@ struct nbls_options {
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
     int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
+    int screen_pretest = 0;    // 1: integer pre-test of a lag group's accumulators before the f32 conversion (epilogue)
+    int screen_tb8 = 0;        // 1: the eight-tile instance wherever one lag block per tile step applies (S == 1)
     int screen_batch_mb = 192;  // quantised-window bytes per unit batch
-    int overlap = 0;           // 1: solve of batch k on a second stream while batch k+1 is correlated
+    int overlap = 0;           // solve of batch k on a second stream while batch k+1 is correlated: 1 on, -1 off, 0 auto (streamed passes of several batches)
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
     int filter_nomfma = 0;     // 1: VALU state kernel
     // ---- developer build only ----
     int ablate = 0;            // skip parts of the screening / verify kernels (timing; results wrong)
     int screen_stamps = 0;     // s_memtime phase stamps of the screening kernel
+    int screen_seed = 0;       // experiment: running maxima of the screening kernel seeded from the previous pass of the same batch
     int lts_stamps = 0;        // ... of the wave-per-unit LTS kernel
     int screen_pad_kb = 0;     // extra LDS per screening workgroup (occupancy experiment)
     int lts_pad_kb = 0;        // extra LDS per LTS workgroup

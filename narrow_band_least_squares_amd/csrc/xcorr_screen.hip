@@ -71,6 +71,8 @@ struct QArgs {
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
+    int seed;                 // developer experiment: running maxima seeded from the previous pass's candidate records
+    int pretest;              // epilogue: integer pre-test on the accumulators before they are converted (option "screen_pretest")
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
     unsigned long long boffp0, boffp1;   // per-channel LDS skew in 16-byte slots (bank-conflict-free B reads): 4 bits per channel,
                               // packed so that a per-lane lookup is a select and a shift, not a load from the argument block
@@ -416,7 +418,9 @@ __device__ inline v4i ld_frag64(const unsigned char* p) {
 // waves per SIMD and may use 256 VGPRs: eight one-block tiles per group, hand-scheduled K loop that walks the A
 // stream once (screen_kloop.inc, NBLS_SCREEN_KLOOP_S1_ASM) — half the LDS bytes per product of the four-tile loop,
 // which ran at 83 % of the LDS bandwidth at that shape.
-template <int TBV>
+// NCV = byte-shifted copies of a sliding channel: 8, or 4 (long windows, QArgs.ncopy; its own instantiation so that the
+// layout is a compile-time constant in the common one — as a run-time value it cost the four-tile kernel 41 spilled VGPRs).
+template <int TBV, int NCV = 8>
 __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) {
     extern __shared__ unsigned char lds[];
     const int tid = threadIdx.x;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
     // (with ONE sliding channel per workgroup its own image is not needed: N-1 slots, slot = partner index)
     const int nimg = NSL == 2 ? N : NP;
-    const int NC = a.ncopy;                          // 8, or 4 (long windows)
+    constexpr int NC = NCV;                          // 8, or 4 (long windows)
     unsigned char* Bimg = lds;
     unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
     int* gmax = (int*)(Acop + (size_t)NSL * 2 * NC * CSA);  // [2][16] order-preserving int image of a float
@@ -480,6 +484,20 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
         gmax[tid] = (int)0x80000000;
         Mj[tid] = (int)0x80000000; cnt[tid] = 0; klo[tid] = 0x7fffffff; khi[tid] = -1; thS[tid] = 0;
         if (tid < 4) qctr[tid] = 0;
+#ifdef NBLS_DEVELOPER
+        // experiment (option "screen_seed", r04): the running maxima start from the screening maxima the PREVIOUS pass over
+        // the same batch left in the candidate records — the best case of any scheme that learns the maximum before the
+        // first round of lag groups (a scout pass, a K-split first round): how much would pruning from the start save?
+        if (a.seed) {
+            const int hs_ = tid >> 4, jj_ = tid & 15, chs_ = NSL * cp + hs_;
+            const int pgb_ = a.pgsz * pg;
+            if (hs_ < NSL && chs_ < N && pgb_ + jj_ < N - 1 && jj_ < a.pgsz) {
+                const int jabs_ = pgb_ + jj_ + (pgb_ + jj_ >= chs_ ? 1 : 0);
+                const float m_ = __int_as_float(a.cand[(((int64_t)ul * N + chs_) * N + jabs_) * CSTRIDE + 4]);
+                if (m_ == m_ && m_ > -3.0e38f) gmax[tid] = f2ord(m_);
+            }
+        }
+#endif
     }
 
     // ---- stage all channels' limbs (zero padded front and back); loads are issued in groups of
@@ -696,7 +714,22 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
 #define DEV_ESTAMP(X)
 #endif
 #define SCREEN_EPILOGUE(NT, ACC)                                                                          \
-    if (colvalid && !(NBLS_ABL(4))) {                                                                    \
+    bool quiet_ = false;                                                                                  \
+    if (a.pretest && colvalid) {                                                                          \
+        /* integer pre-test: every value of this group is <= 16384 max HH + 128 max M in f32 (conversion, */ \
+        /* scaling by powers of two and the rounded sum are monotone); if that bound is below the lane's threshold  */ \
+        /* in EVERY lane, the group holds neither a candidate nor a new maximum: no conversions, no slot work       */ \
+        int hmx_ = ACC[0][0][0], mmx_ = ACC[0][1][0];                                                     \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+            _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                         \
+                hmx_ = ACC[t][0][reg] > hmx_ ? ACC[t][0][reg] : hmx_;                                     \
+                mmx_ = ACC[t][1][reg] > mmx_ ? ACC[t][1][reg] : mmx_;                                     \
+            }                                                                                             \
+        const float bound_ = 16384.0f * (float)hmx_ + 128.0f * (float)mmx_;                               \
+        quiet_ = __builtin_amdgcn_ballot_w64(!(bound_ < lmax - theta)) == 0;                              \
+        if (quiet_) { const float gm_ = ord2f(gmaxh[jj]); if (gm_ > lmax) lmax = gm_; }                   \
+    }                                                                                                     \
+    if (colvalid && !quiet_ && !(NBLS_ABL(4))) {                                                         \
         float v[NT * 4];                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
             _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                                           \
@@ -757,7 +790,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
             }
             p = pdraw;
             if (p >= ngrp4) break;
-            may_prune = p >= nw;
+            may_prune = p >= nw || a.seed;       // (a.seed: developer experiment, see the top of the kernel)
         } else {
             if (rnd * nw >= ngrp4) break;
             p = rnd * nw + ((rnd & 1) ? (nw - 1 - wvu) : wvu);
@@ -1487,6 +1520,8 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     a.lag = h->d_lag;
     a.cmax = h->d_cmax;
     a.dyn = h->opt.screen_static ? 0 : 1;
+    a.pretest = h->opt.screen_pretest ? 1 : 0;
+    a.seed = h->opt.screen_seed ? 1 : 0;
     {
         const unsigned long long d = (unsigned long long)(a.WP / 32 + 2);      // exact for every index below 2^32 / d
         a.tab_inv = (unsigned int)(((1ull << 32) + d - 1) / d);
@@ -1517,9 +1552,10 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     }
     lds += (size_t)h->opt.screen_pad_kb * 1024;                                                      // developer: occupancy experiment
     // eight-tile instance: one lag block per tile step and a CU per workgroup (two waves per SIMD: 256 VGPRs)
-    const bool tb8 = a.S == 1 && lds > 80 * 1024 && !h->opt.screen_tb4 && a.ncopy == 8;
-    hipError_t e = hipFuncSetAttribute(tb8 ? (const void*)screen_kernel<8> : (const void*)screen_kernel<4>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (option screen_tb8: the eight-tile instance wherever S == 1, also for workgroups that would fit a CU twice)
+    const bool tb8 = a.S == 1 && (lds > 80 * 1024 || h->opt.screen_tb8) && !h->opt.screen_tb4 && a.ncopy == 8;
+    const void* skern = tb8 ? (const void*)screen_kernel<8, 8> : (a.ncopy == 4 ? (const void*)screen_kernel<4, 4> : (const void*)screen_kernel<4, 8>);
+    hipError_t e = hipFuncSetAttribute(skern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t vlds = ((size_t)N * gW + 2) * sizeof(double);   // + the zero slot
     if (vlds <= 158 * 1024) {
@@ -1598,8 +1634,10 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
         if (ev) (void)hipEventRecord(ev[1], h->stream);
         const int ngrp = (a.nu + 7) / 8;
         // 8 waves: two sliding channels x 4, or one channel x 8
-        if (tb8) hipLaunchKernelGGL(screen_kernel<8>, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
-        else hipLaunchKernelGGL(screen_kernel<4>, dim3(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp), dim3(512), lds, h->stream, a);
+        const dim3 sgrid(8 * ((N + a.nsl - 1) / a.nsl) * a.npg, ngrp);
+        if (tb8) hipLaunchKernelGGL((screen_kernel<8, 8>), sgrid, dim3(512), lds, h->stream, a);
+        else if (a.ncopy == 4) hipLaunchKernelGGL((screen_kernel<4, 4>), sgrid, dim3(512), lds, h->stream, a);
+        else hipLaunchKernelGGL((screen_kernel<4, 8>), sgrid, dim3(512), lds, h->stream, a);
         if (ev) (void)hipEventRecord(ev[2], h->stream);
         if (vdma) {
             const int share = (a.nu + 7) >> 3;

@@ -318,10 +318,12 @@ def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
             h.set_option('overlap', 1)
             ov = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True, groups=1)
             st_ov = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True)
+            h.set_option('overlap', -1)
+            st_one = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True)
         finally:
             h.set_option('overlap', 0)
         st = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True)
-        for other in (ov, st_ov, st):
+        for other in (ov, st_ov, st_one, st):
             for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'lag', 'z', 'mask'):
                 np.testing.assert_array_equal(getattr(other, k), getattr(base, k), err_msg=k)
 

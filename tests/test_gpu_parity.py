@@ -329,12 +329,12 @@ def test_kernel_variants_agree(monkeypatch):
     try:
         r_gen = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=2, **kw)
         # the other identical-result switches of the library, all at once
-        for key in ('screen_tb4', 'screen_nsl1', 'screen_static', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
+        for key in ('screen_tb4', 'screen_nsl1', 'screen_static', 'screen_pretest', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
             h.set_option(key, 1)
         h.set_option('lts_impl', 0)
         r_alt = engine.process(data, fs, t0, c['rij'], edges, [30.0, 20.0, 10.0], 0.5, 0.5, 'butter', 2, 0.01, xcorr_impl=3, **kw)
     finally:
-        for key in ('lts_impl', 'screen_tb4', 'screen_nsl1', 'screen_static', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
+        for key in ('lts_impl', 'screen_tb4', 'screen_nsl1', 'screen_static', 'screen_pretest', 'filter_nofuse', 'filter_nomfma', 'lts_generic_h'):
             h.set_option(key, 0)
     np.testing.assert_array_equal(r_alt.lag, r_mfma.lag)
     for k in ('vel', 'baz', 'weights'):
@@ -407,6 +407,8 @@ def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
         outs['streamed'] = narrow_band_least_squares(*args, rij=c['rij'])
         nbatch = h.result_batches()
         assert nbatch >= 3, nbatch
+        h.set_option('overlap', -1)                  # (0 = auto: the solves of a several-batch streamed pass go to the second stream)
+        outs['streamed, solves behind their batch on one stream'] = narrow_band_least_squares(*args, rij=c['rij'])
         h.set_option('overlap', 1)
         outs['overlap'] = narrow_band_least_squares(*args, rij=c['rij'])
         # the engine-level entry with the side arrays (fetched after the last batch)
@@ -416,7 +418,7 @@ def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
         seen = []
         r_s = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'][:nb], 0.5, alpha, 'butter', 2, 0.01,
                              units_done=lambda res, u0, u1: seen.append((u0, u1)), **kw)
-        h.set_option('overlap', 0)
+        h.set_option('overlap', -1)
         h.set_option('screen_batch_mb', 192)
         r_w = engine.process(data, fs, t0, c['rij'], edges, c['WINLEN_list'][:nb], 0.5, alpha, 'butter', 2, 0.01, groups=1, **kw)
     finally:
