@@ -1074,6 +1074,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"lts_impl", &nbls_options::lts_impl, false},
         {"lts_generic_h", &nbls_options::lts_generic_h, false},
         {"lts_coop_threads", &nbls_options::lts_coop_threads, false},
+        {"lts_sample_its", &nbls_options::lts_sample_its, false},
         {"screen_nsl1", &nbls_options::screen_nsl1, false},
         {"screen_static", &nbls_options::screen_static, false},
         {"screen_tb4", &nbls_options::screen_tb4, false},

@@ -26,6 +26,7 @@ struct nbls_options {
     int lts_impl = 0;          // 0 auto; 1 lane-per-start generic LTS kernel everywhere; 3 generic only where no register kernel exists
     int lts_generic_h = 0;     // 1: the register LTS kernel without the h-specialised instantiation
     int lts_coop_threads = 0;  // > 0: workgroup size (64..512) of the large-array LTS kernel (solve_bucket.inc)
+    int lts_sample_its = 0;    // large-array LTS kernel: the first n selections of a start take the coarse sample pass (0: all of them, < 0: none)
     int screen_nsl1 = 0;       // 1: one sliding channel per screening workgroup
     int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one

@@ -60,6 +60,7 @@ struct SArgs {
     double zero_scale;
     int use_absr;
     int u0;                // first unit of this launch (unit batches of the pipelined path)
+    int nsample;           // large-array kernel: selections per start centred by the sample histogram (option lts_sample_its)
     unsigned long long* stamps;   // developer (NBLS_LTS_STAMPS=1): 8 s_memtime stamps per wave, else NULL
     int stamp_waves;
     int stamp_mode;        // developer: 2 = the large-array kernel records every wave's busy cycles instead of thread 0's accounts
@@ -1410,6 +1411,7 @@ static hipError_t solve_range_impl(nbls_handle* h, int64_t u0, int64_t nu, hipSt
     a.rew = h->d_rew;
     a.quantile = h->ltsp.quantile;
     a.zero_scale = h->ltsp.zero_scale;
+    a.nsample = h->opt.lts_sample_its > 0 ? h->opt.lts_sample_its : (h->opt.lts_sample_its < 0 ? 0 : 1000);
     a.stamps = nullptr;
     a.stamp_waves = 0;
     {

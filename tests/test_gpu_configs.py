@@ -276,14 +276,15 @@ def test_partner_groups_extend_the_screening_correlator_to_long_windows(nchans, 
 
 
 def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
-    """example.py's adaptive windows 60 -> 30 s at 100 Hz in ONE call, plus a 90 s band (W = 9000: beyond what the
-    screening kernel can hold even with two partners per group): every band of a screenable window length is screened,
-    only the 90 s band runs on the general correlator — no longer the whole plan.  Rows against the oracle."""
+    """example.py's adaptive windows 60 -> 30 s at 100 Hz in ONE call, plus a 140 s band (W = 14 000: beyond what the
+    screening kernel can hold even with four copies and two partners per group, ~13 000): every band of a screenable
+    window length is screened, only the 140 s band runs on the general correlator (windows read from global memory:
+    they do not fit a CU's LDS either) — not the whole plan.  Rows against the oracle."""
     from narrow_band_least_squares_amd import helpers
     fs, nchans = 100.0, 8
     rij = synthetic.array_geometry(nchans, 1.0, seed=5)
     data = synthetic.plane_wave(rij, 40000, fs, 0.1, 5.0, seed=21)
-    winlens = [90.0] + helpers.get_winlenlist('adaptive', 4, 50, 60, 30)
+    winlens = [140.0] + helpers.get_winlenlist('adaptive', 4, 50, 60, 30)
     edges = [(0.1, 0.3), (0.3, 0.6), (0.6, 1.2), (1.2, 2.4), (2.4, 4.8)]
     h = engine.get_handle()
     h.set_profiling(True)
