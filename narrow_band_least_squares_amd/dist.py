@@ -47,6 +47,36 @@ def shard_bands(costs, world):
     return [sorted(x) for x in out]
 
 
+def shard_bands_contiguous(costs, world):
+    """Partition into ``world`` CONTIGUOUS band ranges of about equal cost (cut where the running cost passes k / world of
+    the total) -> list (per rank) of ascending band indices; with at least as many bands as ranks nobody is left empty."""
+    nb = len(costs)
+    cum = np.concatenate(([0.0], np.cumsum(np.asarray(costs, dtype=np.float64))))
+    cuts = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        b = int(np.searchsorted(cum, target))
+        if b > 0 and b <= nb and target - cum[b - 1] < cum[b] - target:
+            b -= 1                                   # the nearer of the two band boundaries
+        b = min(max(b, cuts[-1] + (1 if nb >= world else 0)), nb - (world - r if nb >= world else 0))
+        cuts.append(max(b, cuts[-1]))
+    cuts.append(nb)
+    return [list(range(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
+def plan_shards(costs, world):
+    """The band shares of a sharded call: contiguous ranges when they balance about as well as the LPT partition (within
+    5 % of its largest share) — rank order is then band order, and the process that drives all GPUs can build the
+    dropped-element dictionary from each GPU's streamed rows while the passes are still running — else LPT.
+    Deterministic: every rank of a launcher job computes the same shares.  -> (shards, contiguous flag)."""
+    lpt = shard_bands(costs, world)
+    con = shard_bands_contiguous(costs, world)
+    load = lambda sh: max(sum(costs[b] for b in s) for s in sh) if sh else 0.0      # noqa: E731
+    if load(con) <= 1.05 * load(lpt):
+        return con, True
+    return lpt, False
+
+
 def env_rank():
     """(rank, world, local_rank) as a launcher exported them, else (0, 1, 0)."""
     try:

@@ -230,7 +230,7 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         nb_block = NBANDS
     else:
         costs = dist.band_costs(npts, fs, [WINLEN_list[b] for b in bands], WINOVER, npairs)
-        shards = dist.shard_bands(costs, world)
+        shards, contiguous = dist.plan_shards(costs, world)
         nb_block = max(1, max(len(sh) for sh in shards))
     block_bytes = (nb_block * vector_len * unit_bytes + 7) // 8 * 8 + 8       # + the status word
 
@@ -240,8 +240,16 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         if err:
             raise err[0]
 
+    # One process drives every GPU and the shares are contiguous band ranges: every pass also STREAMS its rows to the host
+    # (nbls_stream_results), and the dropped-element dictionary — one entry per window, ~130 ns each under the GIL: 6.5 ms at
+    # the benchmark's shape, more than an eighth of a GPU pass — is built rank by rank (= band by band) while the GPUs
+    # are still working.  The grids still arrive through the ONE RCCL gather below.
+    use_stream = False
     if status == 0:
         cap = max(1, engine.max_bands_per_pass(nchans, npts))      # filtered bands one pass may keep in HBM
+        use_stream = (not by_windows and ALPHA < 1.0 and contiguous and group.root == 0 and len(group.handles) == world
+                      and engine.streamed_default() and max(len(sh) for sh in shards) <= cap
+                      and all(hasattr(hd, 'wait_result_batch') for hd in group.handles))
 
         def start(i, hd):
             r = group.ranks[i]
@@ -249,7 +257,7 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
             wsl = (r, world) if by_windows else None
             if len(mine) <= cap:
                 engine.launch(hd, rows, prep, bands=None if by_windows else mine, window_slice=wsl, reserve_bytes=block_bytes,
-                              trace_ready=True, before_execute=lambda: landed(i))
+                              trace_ready=True, before_execute=lambda: landed(i), stream=use_stream)
                 return
             # the rank's share does not fit the HBM budget of one pass (NBLS_MAX_FILTERED_GB): consecutive passes of
             # <= cap bands, each fetched to the host; the assembled block goes back to the GPU for the ONE gather
@@ -289,6 +297,33 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         except Exception as e:
             status, failure = 1, e
 
+    stdict_streamed = None
+    if use_stream and status == 0:
+        # rank order = band order: rank 0's batches first (the later ranks' rows wait in their pinned mirrors meanwhile)
+        try:
+            MBs = prep.mask_bytes
+            cum = np.concatenate(([0], np.cumsum(prep.nwin))).astype(np.int64)
+            smask = np.zeros((NBANDS, vector_len, MBs), dtype=np.uint8)
+            stdict_streamed = engine.new_stdict(engine.n_keys(keys))
+            cache = engine.new_pattern_cache()
+            for i, hd in enumerate(group.handles):
+                sh = shards[group.ranks[i]]
+                if not sh:
+                    continue
+                b0, b1 = sh[0], sh[-1] + 1
+                for k in range(hd.result_batches()):
+                    u0, u1, c0, c1, _, msrc = hd.wait_result_batch(k)
+                    if c1 > c0:
+                        smask[b0:b1].reshape(-1, MBs)[c0:c1] = msrc[c0:c1]
+                    if u1 > u0:
+                        engine.stdict_from_mask(smask, prep.nwin, prep.pair_idx, nchans, keys, into=stdict_streamed, cache=cache,
+                                                units=(int(cum[b0]) + u0, int(cum[b0]) + u1))
+            if 'size' not in stdict_streamed:
+                stdict_streamed['size'] = nchans
+            engine.release_later(cache)
+        except Exception as e:      # noqa: BLE001 - reported through the gather's status word like every other local failure
+            status, failure, stdict_streamed = 1, e, None
+
     blocks = group.gather(block_bytes, status)          # the ONE collective
     if failure is not None:
         raise failure
@@ -319,6 +354,6 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         stdict_all = None
         sig_tau_array = grids[3]
     else:
-        stdict_all = engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys)
+        stdict_all = stdict_streamed if stdict_streamed is not None else engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys)
         sig_tau_array = np.zeros((NBANDS, vector_len))
     return (grids[0], grids[1], grids[2], t_array, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)

@@ -50,13 +50,46 @@ class FakeHandle:
         self.block = np.array(block, dtype=np.uint8)
         self.loaded = True
 
+    # streamed passes (the one-process form with contiguous shares): the block arrives in batches that cut through bands
+    streamed = False
+    waited = 0
+
+    def _batches(self):
+        U = sum(self.nwin_share)
+        cuts = sorted({0, U} | {int(0.37 * U), int(0.8 * U)})
+        return list(zip(cuts[:-1], cuts[1:]))
+
+    def result_batches(self):
+        return len(self._batches()) if self.streamed else 0
+
+    def wait_result_batch(self, k):
+        assert self.streamed
+        nb, VL, MB = self.last_shape
+        u0, u1 = self._batches()[k]
+
+        def cell(u):
+            off = 0
+            for b, n in enumerate(self.nwin_share):
+                if u < off + n:
+                    return b * VL + (u - off)
+                off += n
+            raise AssertionError(u)
+        c0, c1 = (cell(u0), cell(u1 - 1) + 1) if u1 > u0 else (0, 0)
+        cells = nb * VL
+        g = np.full((4, cells), np.nan)                                   # what no batch has delivered yet is undefined
+        m = np.full((cells, MB), 0xA5, dtype=np.uint8)
+        g[:, c0:c1] = np.frombuffer(self.block[:32 * cells].tobytes(), dtype=np.float64).reshape(4, cells)[:, c0:c1]
+        m[c0:c1] = self.block[32 * cells:].reshape(cells, MB)[c0:c1]
+        self.waited += 1
+        return u0, u1, c0, c1, g, m
+
 
 def make_fake_launch(gold, fail_rank=None, rank_of=None):
     """engine.launch stand-in: the oracle computes the share, the block is left on the fake handle."""
     edges_all = nbls_mod._band_edges(list(gold['freqlist']), str(gold['band_type']), range(len(gold['num_compute'])))
 
     def fake_launch(h, data, prep, bands=None, upload=True, window_slice=None, xcorr_impl=0, reserve_bytes=0,
-                    trace_from=None, trace_ready=False, after=None, before_execute=None):
+                    trace_from=None, trace_ready=False, after=None, before_execute=None, stream=False, uncert=False):
         if fail_rank is not None and rank_of(h) == fail_rank:
             raise ValueError('injected failure on rank %d' % fail_rank)
         if before_execute is not None:       # the real launch joins the upload thread between plan and execute
@@ -86,6 +119,8 @@ def make_fake_launch(gold, fail_rank=None, rank_of=None):
         assert mask.shape[-1] == MB
         h.block = np.frombuffer(grids.tobytes() + mask.tobytes(), dtype=np.uint8)
         h.last_shape = (nb, VL, MB)
+        h.streamed = bool(stream)
+        h.nwin_share = [int(prep.nwin[b]) for b in idx]
         assert reserve_bytes >= len(h.block) + 8
     return fake_launch
 
@@ -171,6 +206,11 @@ def run_single_process(gold_name, mode, world, monkeypatch, bands_per_pass=None)
     nb = call_and_compare(gold, group)
     if bands_per_pass:
         assert any(getattr(h, 'loaded', False) and h.rounds >= 2 for h in group.handles), 'no rank needed several rounds'
+    elif mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS', '1') != '0':
+        # contiguous band shares under LTS: the dictionary was built from the ranks' streamed batches, in rank order
+        assert all(h.streamed and h.waited == h.result_batches() for h in group.handles if h.block is not None), 'not streamed'
+    else:
+        assert not any(h.waited for h in group.handles)
     return nb
 
 

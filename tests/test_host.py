@@ -126,6 +126,16 @@ def test_shard_bands_is_a_balanced_partition():
         assert max(loads) <= 1.2 * (sum(costs) / world)
     assert dist.shard_bands([1.0, 1.0], 4) == [[0], [1], [], []]
     assert dist.env_rank()[1] == 1
+    # contiguous shares (rank order = band order: the one-process form streams the dictionary rank by rank) wherever they
+    # balance within 5 % of the LPT partition
+    for world in (1, 2, 3, 4, 8):
+        shards, contiguous = dist.plan_shards(costs, world)
+        assert sorted(b for s in shards for b in s) == list(range(48))
+        if contiguous:
+            assert all(s == list(range(s[0], s[-1] + 1)) for s in shards if s) and [s[0] for s in shards if s] == sorted(s[0] for s in shards if s)
+            assert max(sum(costs[b] for b in s) for s in shards) <= 1.05 * max(sum(costs[b] for b in s) for s in dist.shard_bands(costs, world))
+    assert dist.plan_shards([1.0] * 48, 8) == ([list(range(6 * r, 6 * r + 6)) for r in range(8)], True)
+    assert dist.shard_bands_contiguous([5, 1, 1, 1], 3) == [[0], [1], [2, 3]]
 
 
 @pytest.mark.parametrize('gold,mode,world', [('loop_ols_butter_linear', 'bands', 3), ('loop_lts_butter_octave', 'bands', 2),
