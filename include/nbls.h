@@ -288,7 +288,7 @@ int nbls_comm_destroy(nbls_handle* h);
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
  *   "lts_generic_h", "lts_coop_threads", "screen_tb4", "screen_nsl1", "screen_static", "screen_batch_mb",
  *   "overlap" (the solve of a unit batch on a second stream beside the next batch's correlation: 1 on, -1 off, 0 auto = on
- *   for streamed passes of several batches), "filter_nofuse",
+ *   for streamed passes of several small batches), "filter_nofuse",
  *   "filter_nomfma";
  *   "stream_priority" (applied at once; the handle must be idle): 0 normal, > 0 lower, < 0 higher, clamped to the
  *   device's range — for several handles of one GPU whose passes run side by side.

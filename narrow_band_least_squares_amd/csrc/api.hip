@@ -752,11 +752,15 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     // per-batch solves: behind each unit batch of the correlation stage (streamed results: a batch's rows are complete
     // while later batches are still being correlated), on the second stream with option "overlap"
     h->fuse_solve = ((stage_mask & 6) == 6) && h->xcorr_impl == 3 && (h->opt.overlap > 0 || h->stream_results);
-    // option "overlap": 1 on, -1 off, 0 auto = on for a streamed pass of several unit batches (measured r04, device
-    // pass: cfg-3 14.7 -> 14.3 ms, cfg-1b 0.95 -> 0.75, cfg-5 174.6 -> 169.0; a single-batch pass only pays the join:
-    // cfg-2 0.93 -> 0.96)
-    const bool several = h->nunits > h->screen_batch || h->wgroups.size() > 1;
-    h->solve_on_stream2 = h->fuse_solve && h->stream2 && (h->opt.overlap > 0 || (h->opt.overlap == 0 && h->stream_results && several));
+    // option "overlap": 1 on, -1 off, 0 auto = on for a streamed pass of several SMALL unit batches (under 1024 units on
+    // average: adaptive windows give every window length a batch of its own, and a batch of a few dozen units is all
+    // launch latency and drain — device pass of cfg-1b 0.95 -> 0.75 ms).  Big batches gain 1.5-3 % (cfg-3 14.7 -> 14.3 ms,
+    // cfg-5 174.6 -> 169.0) at the price of kernels whose measured durations include their neighbour's: left off there.
+    int64_t nbatch_est = 0;
+    for (const nbls_wgroup& g : h->wgroups)
+        if (g.u1 > g.u0) nbatch_est += g.screen && h->screen_batch > 0 ? (g.u1 - g.u0 + h->screen_batch - 1) / h->screen_batch : 1;
+    const bool small_batches = nbatch_est > 1 && h->nunits / nbatch_est < 1024;
+    h->solve_on_stream2 = h->fuse_solve && h->stream2 && (h->opt.overlap > 0 || (h->opt.overlap == 0 && h->stream_results && small_batches));
     // (a caller that did not wait for every batch of the previous pass: its copies read the block this pass clears)
     if (!h->rbatches.empty() && h->cstream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->rev[2 * (h->rbatches.size() - 1) + 1], 0));
     h->rbatches.clear();
