@@ -286,7 +286,8 @@ int nbls_comm_destroy(nbls_handle* h);
 /* Per-handle switches, read by the next nbls_plan / nbls_execute.  Every key of the shipped library selects
  * between implementations that give IDENTICAL results (A/B timing; tests that check kernels against each other):
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
- *   "lts_generic_h", "lts_coop_threads", "screen_tb4", "screen_nsl1", "screen_static", "screen_batch_mb",
+ *   "lts_generic_h", "lts_coop_threads", "lts_sample_its", "screen_tb4", "screen_tb8", "screen_nsl1", "screen_static",
+ *   "screen_pretest", "screen_batch_mb", "solve_min_units" (units a per-batch solve / streamed result batch covers at least),
  *   "overlap" (the solve of a unit batch on a second stream beside the next batch's correlation: 1 on, -1 off, 0 auto = on
  *   for streamed passes of several small batches), "filter_nofuse",
  *   "filter_nomfma";

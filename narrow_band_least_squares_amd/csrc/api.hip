@@ -1086,6 +1086,7 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_tb8", &nbls_options::screen_tb8, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
+        {"solve_min_units", &nbls_options::solve_min_units, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
         {"filter_nomfma", &nbls_options::filter_nomfma, false},
         {"ablate", &nbls_options::ablate, true},

@@ -33,6 +33,7 @@ struct nbls_options {
     int screen_pretest = 0;    // 1: integer pre-test of a lag group's accumulators before the f32 conversion (epilogue)
     int screen_tb8 = 0;        // 1: the eight-tile instance wherever one lag block per tile step applies (S == 1)
     int screen_batch_mb = 192;  // quantised-window bytes per unit batch
+    int solve_min_units = 0;   // > 0: units a per-batch solve (and a streamed result batch) covers at least (default 8192)
     int overlap = 0;           // solve of batch k on a second stream while batch k+1 is correlated: 1 on, -1 off, 0 auto (streamed passes of several small batches)
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
     int filter_nomfma = 0;     // 1: VALU state kernel

@@ -1597,6 +1597,8 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
             h->bev.push_back(ev);
         }
     }
+    const int64_t kMinSolveUnits = h->opt.solve_min_units > 0 ? h->opt.solve_min_units : 8192;   // units per solve launch and result batch, at least (see below)
+    int64_t solve_from = ub;
     for (int64_t u0 = ub; u0 < ue; u0 += batch) {
         a.u0 = (int)u0;
         a.nu = (int)((ue - u0) < batch ? (ue - u0) : batch);
@@ -1648,10 +1650,13 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);
-        if (h->fuse_solve) {
-            // the solve of this batch right behind it: on the same stream (the batch's rows are complete, and on their
-            // way to the host, while the next batch is correlated), or — option "overlap" — on the second stream
-            // (VALU-bound) beside the next batch's quantiser / screening kernel (matrix pipe + LDS)
+        if (h->fuse_solve && (u0 + a.nu - solve_from >= kMinSolveUnits || u0 + a.nu >= ue)) {
+            // the solve of the correlated units right behind them: on the same stream (their rows are complete, and on
+            // their way to the host, while the next batch is correlated), or — option "overlap" — on the second stream
+            // (VALU-bound) beside the next batch's quantiser / screening kernel (matrix pipe + LDS).  Screening batches
+            // are sized in BYTES of quantised windows: with long windows or many elements a batch is a few thousand units
+            // (cfg-4: 2 091), under three rounds of the large-array LTS kernel's workgroups — such batches are solved
+            // several at a time (r04: the per-batch solves had cost cfg-4's share 37 -> 44.6 ms)
             hipStream_t ss = h->stream;
             if (h->solve_on_stream2) {
                 while ((int64_t)h->pev.size() <= launches + 1) {
@@ -1663,10 +1668,11 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
                 (void)hipStreamWaitEvent(h->stream2, h->pev[launches], 0);
                 ss = h->stream2;
             }
-            hipError_t se = nbls_launch_solve_range(h, u0, a.nu, ss);
+            hipError_t se = nbls_launch_solve_range(h, solve_from, u0 + a.nu - solve_from, ss);
             if (se != hipSuccess) return se;
             if (ev) (void)hipEventRecord(ev[4], ss);
-            if ((se = nbls_queue_result_batch(h, u0, u0 + a.nu, ss)) != hipSuccess) return se;
+            if ((se = nbls_queue_result_batch(h, solve_from, u0 + a.nu, ss)) != hipSuccess) return se;
+            solve_from = u0 + a.nu;
         } else if (ev) (void)hipEventRecord(ev[4], h->stream);
         ++launches;
     }

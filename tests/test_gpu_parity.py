@@ -404,6 +404,7 @@ def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
     outs = {}
     try:
         h.set_option('screen_batch_mb', 1)
+        h.set_option('solve_min_units', 1)           # (default: small screening batches are solved several at a time)
         outs['streamed'] = narrow_band_least_squares(*args, rij=c['rij'])
         nbatch = h.result_batches()
         assert nbatch >= 3, nbatch
@@ -424,6 +425,7 @@ def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
     finally:
         h.set_option('overlap', 0)
         h.set_option('screen_batch_mb', 192)
+        h.set_option('solve_min_units', 0)
     assert len(seen) >= 3 and seen[0][0] == 0 and seen[-1][1] == int(r_s.nwin.sum())
     assert all(a[1] == b[0] for a, b in zip(seen[:-1], seen[1:]))              # consecutive, in order
     for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'mask', 'lag', 'cmax', 'z', 't'):
@@ -452,6 +454,7 @@ def test_streamed_batches_through_the_c_abi():
     h = engine.get_handle()
     try:
         h.set_option('screen_batch_mb', 1)
+        h.set_option('solve_min_units', 1)
         engine.launch(h, data, prep, stream=True)
         n = h.result_batches()
         assert n >= 2
@@ -493,6 +496,7 @@ def test_streamed_batches_through_the_c_abi():
             assert not np.any(side[k]), k
     finally:
         h.set_option('screen_batch_mb', 192)
+        h.set_option('solve_min_units', 0)
 
 
 @pytest.mark.parametrize('nchans,winlen', [(3, 20.0), (4, 12.5), (5, 30.0), (7, 9.0), (9, 25.0), (12, 15.0), (16, 40.0),
