@@ -236,24 +236,20 @@ def pair_table(nchans):
     return np.array([(i, j) for i in range(nchans - 1) for j in range(i + 1, nchans)], dtype=np.int32)
 
 
-_co_array_cache = {}
+@functools.lru_cache(maxsize=8)
+def _co_array_cached(shape, raw):
+    out = _co_array(np.frombuffer(raw, dtype=np.float64).reshape(shape))
+    for a in out:
+        a.flags.writeable = False
+    return out
 
 
 def co_array(rij):
     """rij (2, N) km -> xij (P, 2) = r_i - r_j, pair table (P, 2), pinv(xij) (2, P).  A pure function of the
-    coordinates: the last few geometries are kept (read-only arrays)."""
+    coordinates: the last few geometries are kept (read-only arrays; ``functools.lru_cache``: safe under the host threads
+    that drive several handles — the dict with manual eviction it replaces was not)."""
     rij = np.ascontiguousarray(rij, dtype=np.float64)
-    key = (rij.shape, rij.tobytes())
-    hit = _co_array_cache.get(key)
-    if hit is not None:
-        return hit
-    out = _co_array(rij)
-    for a in out:
-        a.flags.writeable = False
-    if len(_co_array_cache) >= 8:
-        _co_array_cache.pop(next(iter(_co_array_cache)))
-    _co_array_cache[key] = out
-    return out
+    return _co_array_cached(rij.shape, rij.tobytes())
 
 
 def _co_array(rij):
