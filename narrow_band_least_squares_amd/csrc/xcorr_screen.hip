@@ -460,7 +460,11 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     // B-fragment reads are bank-conflict free for every sliding channel), then per sliding channel the
     // 8 shifted copies [2][2 limbs][8][CSA], then the shared running maxima
     // (with ONE sliding channel per workgroup its own image is not needed: N-1 slots, slot = partner index)
-    const int nimg = NSL == 2 ? N : NP;
+    // images staged: all N channels (two sliding channels, every partner in this workgroup), or — two sliding channels AND
+    // partner groups (r04: 17+ elements with short windows) — the group's channels img0 .. img0 + pgsz (one more than a
+    // sliding channel's partners: each of the two skips itself), or one sliding channel's NP partners
+    const int img0 = (NSL == 2 && NPG > 1) ? pgbase : 0;
+    const int nimg = NSL == 2 ? (NPG > 1 ? ((a.pgsz + 1) < (N - pgbase) ? (a.pgsz + 1) : (N - pgbase)) : N) : NP;
     constexpr int NC = NCV;                          // 8, or 4 (long windows)
     unsigned char* Bimg = lds;
     unsigned char* Acop = Bimg + (size_t)nimg * 2 * CSB;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = row0 + rr * nwaves;
                 const int slot = row >> 1, limb = row & 1;
-                const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
+                const int ch = NSL == 2 ? img0 + slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
                 const int8_t* src = a.qbuf + (((int64_t)ul * N + (row < nrowB ? ch : 0)) * 2 + limb) * WP;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = row0 + rr * nwaves;
                 const int slot = row >> 1, limb = row & 1;
-                const int ch = NSL == 2 ? slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
+                const int ch = NSL == 2 ? img0 + slot : pgbase + slot + (pgbase + slot >= ci0 ? 1 : 0);
                 unsigned char* dst = Bimg + ((size_t)slot * 2 + limb) * CSB + 16 * boff_of(a, row < nrowB ? ch : 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
     const int arow = NC == 8 ? (lane & 7) : (lane & 3), aoff = NC == 8 ? (lane & 8) : ((lane & 12));
     const unsigned char* pAh = Ah + (size_t)arow * CSA + 16 * g + aoff;   // + n' + D0
     const unsigned char* pAl = Al + (size_t)arow * CSA + 16 * g + aoff;
-    const int jslot = NSL == 2 ? j : jj;
+    const int jslot = NSL == 2 ? j - img0 : jj;
     const unsigned char* pBh = Bimg + ((size_t)jslot * 2) * CSB + 16 * boff_of(a, j) + PFB + 16 * g - 16 * s;   // + n'
     const unsigned char* pBl = pBh + CSB;
     int* gmaxh = gmax + 16 * half;
@@ -1474,10 +1478,11 @@ bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int*
             // LDS, else one sliding channel (4 waves, N-1 images)
             // + running maxima and merge scalars (6 x 32 ints) + the per-channel records (4 doubles each); the f32 energy tables of the pruning test are added by
             // the caller when they still fit (nbls_screen_tables)
-            const size_t lds2 = (size_t)2 * N * (*CSB) + (size_t)4 * nc * csa + 6 * 128 + 16 + 32 * N + 64;
+            // (partner groups: a workgroup with two sliding channels stages the group's g + 1 channels, not all N)
+            const size_t lds2 = (size_t)2 * (N - 1 <= 16 ? N : g + 1) * (*CSB) + (size_t)4 * nc * csa + 6 * 128 + 16 + 32 * N + 64;
             const size_t lds1 = (size_t)2 * g * (*CSB) + (size_t)2 * nc * csa + 6 * 128 + 16 + 32 * N + 64;
             const bool force1 = h->opt.screen_nsl1 != 0;                         // option: one sliding channel per workgroup
-            if (nc == 8 && g == NPc && lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && N - 1 <= 16 && !force1) { *nsl = 2; *lds = lds2; }
+            if (nc == 8 && g == NPc && lds2 + (size_t)(2 + N) * (*WP / 32 + 2) * 4 <= 80 * 1024 && !force1) { *nsl = 2; *lds = lds2; }
             else { *nsl = 1; *lds = lds1; }
             if (*lds <= 160 * 1024 && *lds >= 1024) return true;
         }
