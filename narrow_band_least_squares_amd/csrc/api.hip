@@ -493,7 +493,7 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         // plan sits on the critical path of a call: the GPU has nothing to do until it is through)
         double* const fwp = FW.data();
         double* const mp = M.data();
-        const int nt = nsections > 0 ? (nbands >= 32 ? 8 : (nbands >= 12 ? 4 : (nbands >= 6 ? 2 : 1))) : 0;
+        const int nt = nsections > 0 ? std::max(1, std::min(12, nbands / 3)) : 0;     // ~3+ bands per thread (a thread costs ~15 us to start)
         auto work = [&](int t) {
             for (int b = t; b < nbands; b += nt)
                 filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,

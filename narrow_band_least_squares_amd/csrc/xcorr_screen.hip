@@ -1198,20 +1198,31 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
     if (tid == 0) vsm[(size_t)N * W] = 0.0;              // the zero slot of wave_dot
     __syncthreads();
     for (int k0 = (NBLS_ABL(64)) ? P : 0; k0 * nwv + wv < P; k0 += 4) {
+        // more than four pairs per wave (big arrays: 62 at 32 elements): the records and norms of the NEXT four pairs are
+        // requested before this group's candidates are evaluated (r04: on demand, every pair waited for a global round
+        // trip of its own — 17.9 ms of cfg-5's pass)
+        int nrecs[4];
+        double nssA[4], nssB[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = wv + (k0 + 4 + q) * nwv;
+            nrecs[q] = 0; nssA[q] = 0.0; nssB[q] = 0.0;
+            if (k < P) {
+                const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
+                const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
+                const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
+                nrecs[q] = lane < 32 ? l1[lane] : l2[lane - 32];
+                nssA[q] = a.qmeta[((int64_t)ul * N + ci) * a.qms];
+                nssB[q] = a.qmeta[((int64_t)ul * N + cj) * a.qms];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = wv + (k0 + q) * nwv;
             if (k >= P) break;
             const int ci = a.pair[2 * k], cj = a.pair[2 * k + 1];
-            int rec = recs[q];
-            double ssa = ssA[q], ssb = ssB[q];
-            if (k0 > 0) {     // more than four pairs per wave (big arrays): load on demand
-                const int32_t* l1 = a.cand + (((int64_t)ul * N + ci) * N + cj) * CSTRIDE;
-                const int32_t* l2 = a.cand + (((int64_t)ul * N + cj) * N + ci) * CSTRIDE;
-                rec = lane < 32 ? l1[lane] : l2[lane - 32];
-                ssa = a.qmeta[((int64_t)ul * N + ci) * a.qms];
-                ssb = a.qmeta[((int64_t)ul * N + cj) * a.qms];
-            }
+            const int rec = recs[q];
+            const double ssa = ssA[q], ssb = ssB[q];
             double best;
             int bestk;
             verify_pair(vsm + (size_t)ci * W, vsm + (size_t)cj * W, vsm + (size_t)N * W, W, rec, ssa, ssb, lane, &best, &bestk);
@@ -1221,6 +1232,8 @@ __global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
                 a.cmax[o] = best / sqrt(ssa * ssb);
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { recs[q] = nrecs[q]; ssA[q] = nssA[q]; ssB[q] = nssB[q]; }
     }
 }
 
