@@ -85,14 +85,16 @@ __device__ inline int nonfinite_argmax(const double* xa, const double* xb, int W
 __device__ inline bool finite_f64(double v) { return fabs(v) < __builtin_inf(); }   // false for NaN and +-Inf
 
 // Arg-max order of the reference for one pair: np.argmax(np.correlate(a, b, 'full') / norm) compares the QUOTIENTS, the
-// first maximum wins.  v: raw dot products, k: np.correlate index, nrm = sqrt(sum a^2 * sum b^2).  Division is monotone,
+// first maximum wins.  v: raw dot products, k: np.correlate index, ss = sum a^2 * sum b^2 (the norm's square: its root is
+// taken only in the rare branch that needs the quotients).  Division is monotone,
 // so raw values more than a few ulps apart order like their quotients; closer ones may share a quotient, and then the
 // SMALLER index wins although its raw value is the smaller one (reachable on periodic inputs).  A total
 // order (quotient descending, index ascending): safe in any reduction tree.
-__device__ inline bool better_q(double v1, int k1, double v2, int k2, double nrm) {
+__device__ inline bool better_q(double v1, int k1, double v2, int k2, double ss) {
     if (v1 == v2) return k1 < k2;
     const double hi = fmax(fabs(v1), fabs(v2));
     if (fabs(v1 - v2) <= 1.0e-15 * hi) {
+        const double nrm = sqrt(ss);
         const double q1 = v1 / nrm, q2 = v2 / nrm;
         return (q1 > q2) || (q1 == q2 && k1 < k2);
     }

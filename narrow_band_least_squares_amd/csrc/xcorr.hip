@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void xcorr_simple_kernel(XArgs a) {
 
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
-    const double nrm_ab = sqrt(ssa * ssb);               // maxima are compared by quotient, like np.argmax(cij / norm)
+    const double nrm_ab = ssa * ssb;                     // (square of the norm) maxima are compared by quotient, like np.argmax(cij / norm): better_q
     const int nl = 2 * W - 1;
     for (int kk = tid; kk < nl; kk += 256) {
         const int d = kk - (W - 1);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
     const double* pb = sm + (size_t)j * CS + PF + kq - 16 * s;    // + n'
     double bestv = -__builtin_inf();
     int bestk = 0x7fffffff;
-    const double nrm_wj = sqrt(wv < j ? nrm[wv] * nrm[j] : nrm[j] * nrm[wv]);    // (product in pair order ci < cj, as in the final division)
+    const double nrm_wj = wv < j ? nrm[wv] * nrm[j] : nrm[j] * nrm[wv];    // (square of the norm; product in pair order ci < cj, as in the final division)
     const int step = 16 * S;
     for (int D0 = 0; D0 < W; D0 += step) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -231,12 +231,12 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
         const int ci = a.pair[2 * tid], cj = a.pair[2 * tid + 1];     // ci < cj
         double bv = -__builtin_inf();
         int bk = 0x7fffffff;
-        const double nrm_p = sqrt(nrm[ci] * nrm[cj]);
+        const double nrm_p2 = nrm[ci] * nrm[cj];
         for (int ss = 0; ss < S; ++ss) {
             const int c1 = (cj - 1) + (N - 1) * ss;     // wave ci, partner cj
-            if (nbls_wave::better_q(cbv[ci * 16 + c1], cbk[ci * 16 + c1], bv, bk, nrm_p)) { bv = cbv[ci * 16 + c1]; bk = cbk[ci * 16 + c1]; }
+            if (nbls_wave::better_q(cbv[ci * 16 + c1], cbk[ci * 16 + c1], bv, bk, nrm_p2)) { bv = cbv[ci * 16 + c1]; bk = cbk[ci * 16 + c1]; }
             const int c2 = ci + (N - 1) * ss;           // wave cj, partner ci
-            if (nbls_wave::better_q(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk, nrm_p)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
+            if (nbls_wave::better_q(cbv[cj * 16 + c2], cbk[cj * 16 + c2], bv, bk, nrm_p2)) { bv = cbv[cj * 16 + c2]; bk = cbk[cj * 16 + c2]; }
         }
         if (!nbls_wave::finite_f64(nrm[ci]) || !nbls_wave::finite_f64(nrm[cj])) {
             // NaN / Inf samples: NumPy's semantics (see wave_ops.h nonfinite_argmax), scanned by this one thread
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void xcorr_mfma_kernel(XArgs a) {
         }
         const int64_t o = ((int64_t)band * a.vector_len + w) * a.npairs + tid;
         a.lag[o] = (W - 1) - bk;
-        a.cmax[o] = bv / nrm_p;
+        a.cmax[o] = bv / sqrt(nrm_p2);
     }
 }
 

@@ -1064,7 +1064,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
                                    double ssa, double ssb, int lane, double* best_out, int* bestk_out, double* scr = nullptr) {
     double best = -__builtin_inf();
     int bestk = 0x7fffffff;
-    const double nrm = sqrt(ssa * ssb);                  // (the maxima are compared as the reference compares them: by quotient)
+    const double nrm = ssa * ssb;                        // (square of the norm: the maxima are compared as the reference compares them, by quotient — better_q)
     if (!nbls_wave::finite_f64(ssa) || !nbls_wave::finite_f64(ssb)) {
         // NaN / Inf samples in a window (gappy trace): the screening saw them as zeros; the answer is NumPy's
         bestk = nbls_wave::nonfinite_argmax(xa, xb, W, lane);
