@@ -1155,7 +1155,7 @@ __device__ inline void verify_pair(const double* xa, const double* xb, const dou
 
 // Block-per-unit variant: the N channel windows are staged once in LDS (N*W*8 bytes), the waves
 // share the unit's pairs.  Used when the windows fit; otherwise verify_kernel reads from global.
-__global__ __launch_bounds__(512) void verify_lds_kernel(QArgs a) {
+__global__ __launch_bounds__(1024) void verify_lds_kernel(QArgs a) {
     extern __shared__ double vsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
     const int P = a.npairs, N = a.nchans;
@@ -1664,7 +1664,8 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
             const int per_xcd = h->num_cus > 0 ? (h->num_cus + 7) / 8 : 32;      // one workgroup per CU
             hipLaunchKernelGGL(verify_dma_kernel, dim3(8 * (share < per_xcd ? share : per_xcd)), dim3(1024), dlds, h->stream, a, vwp, h->nbands);
         } else if (vlds <= 158 * 1024)
-            hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(512), vlds, h->stream, a);
+            // (many pairs per unit: sixteen waves share them — the workgroup has the CU to itself when its windows fill the LDS)
+            hipLaunchKernelGGL(verify_lds_kernel, dim3(xcd_grid(1, a.nu)), dim3(h->npairs > 128 && vlds > 80 * 1024 ? 1024 : 512), vlds, h->stream, a);
         else
             hipLaunchKernelGGL(verify_kernel, dim3((a.nu * h->npairs + 3) / 4), dim3(256), 0, h->stream, a);
         if (ev) (void)hipEventRecord(ev[3], h->stream);
