@@ -44,13 +44,17 @@ fr = np.logspace(-2, np.log10(c['fs'] / 2), 1000)
 w = np.zeros(1000)
 args = (c['WINLEN_list'], c['overlap'], c['alpha'], c['st'], None, None, c['NBANDS'], w, w, c['freqlist'],
         c['band_type'], fr, c['ftype'], c['order'], c['ripple'])
-for rep in range(6):
+HOLD = len(sys.argv) > 2 and sys.argv[2] == 'hold'     # keep every call's result alive (what bench.py's timed loop does)
+kept = []
+for rep in range(12 if HOLD else 6):
     planner.design_cache_clear()
     events.clear()
     T0[0] = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         out = narrow_band_least_squares(*args, rij=c['rij'])
     total = (time.perf_counter() - T0[0]) * 1e3
+    if HOLD:
+        kept.append(out)
     del out
 print('whole call %.2f ms' % total)
 for label, a, b in sorted(events, key=lambda e: e[1]):
