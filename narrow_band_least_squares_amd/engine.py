@@ -20,6 +20,15 @@ except ImportError:                    # not built: the pure-Python equivalents 
 
 _handles = {}
 
+# Scheduling switches of the band-group path of rounds 2-3 and of the host helpers: module attributes, set by tests and
+# tools (they were environment variables until round 4: NBLS_UPLOAD_OVERLAP, NBLS_GROUP_ORDER, NBLS_STREAM_PRIORITY,
+# NBLS_PIPELINE_SPLIT, NBLS_KEY_THREADS).  Results never depend on them.
+UPLOAD_OVERLAP = True      # the trace goes up on a helper thread beside the filter design and the plan
+GROUP_ORDER = True         # band groups: the groups' correlation stages are chained on the GPU (nbls_execute_after)
+STREAM_PRIORITY = True     # band groups: earlier groups on higher-priority streams
+PIPELINE_SPLIT = None      # band groups: explicit shares, e.g. (0.15, 0.5, 0.35)
+KEY_THREADS = None         # threads that format the stdict key text (default: min(4, cores - 1))
+
 
 def default_device():
     """NBLS_DEVICE, else LOCAL_RANK (one process per GPU under torch.distributed.run), else 0."""
@@ -40,7 +49,7 @@ def get_handle(device=None, slot=0):
         h = Handle(dev)
         # the groups' passes run side by side; the earlier group's workgroups are dispatched first so that its rows
         # land while the later groups still keep the GPU busy (the host builds that group's dictionary meanwhile)
-        if os.environ.get('NBLS_STREAM_PRIORITY', '1') != '0':
+        if STREAM_PRIORITY:
             h.set_option('stream_priority', min(int(slot), 2) - 1)
         _handles[key] = h
     return h
@@ -422,7 +431,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     # shape (set_trace_shape), only nbls_execute needs the samples
     uploader = None
     upload_error = []
-    if upload and handle is None and (cap >= 1 or prefiltered) and os.environ.get('NBLS_UPLOAD_OVERLAP', '1') != '0':
+    if upload and handle is None and (cap >= 1 or prefiltered) and UPLOAD_OVERLAP:
         h0 = get_handle(device, 0)
         up_rows = list(np.ascontiguousarray(data, dtype=np.float64)) if isinstance(data, np.ndarray) else data
         h0.set_trace_shape(nchans, npts, fs)
@@ -458,11 +467,11 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         streamed = groups is None and window_slice is None and streamed_default()
         ngroups = 1 if ((prefiltered or handle is not None or not upload) and groups is None) or streamed else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
         ngroups = max(1, min(ngroups, nb))
-        # contiguous band groups by unit count.  NBLS_PIPELINE_SPLIT="0.15,0.5,0.35": explicit shares (a small first
+        # contiguous band groups by unit count.  engine.PIPELINE_SPLIT = (0.15, 0.5, 0.35): explicit shares (a small first
         # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)
-        split = os.environ.get('NBLS_PIPELINE_SPLIT')
+        split = PIPELINE_SPLIT
         if split and groups is None and ngroups > 1:
-            shares = [max(0.0, float(x)) for x in split.split(',') if x.strip()]
+            shares = [max(0.0, float(x)) for x in split]
             ngroups = max(1, min(len(shares), nb))
             shares = np.cumsum(shares[:ngroups]) / max(1e-30, float(np.sum(shares[:ngroups])))
         else:
@@ -588,7 +597,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             # dictionary of group k is built while groups k+1.. are still running.  Left to itself the GPU shares
             # itself between the passes and all of them land together at the end (stream priorities alone did the
             # job on some boxes and not on others)
-            ordered = launched and not sequential and os.environ.get('NBLS_GROUP_ORDER', '1') != '0'
+            ordered = launched and not sequential and GROUP_ORDER
             launch(h, data, prep, upload=upload, window_slice=window_slice, uncert=want_uncert,
                    xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
                    trace_ready=early, after=launched[-1][0] if ordered else None,
@@ -637,9 +646,8 @@ def time_key_text(t, nwin, prefixes=None):
 
 
 def _key_threads():
-    env = os.environ.get('NBLS_KEY_THREADS')
-    if env:
-        return max(1, int(env))
+    if KEY_THREADS:
+        return max(1, int(KEY_THREADS))
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):

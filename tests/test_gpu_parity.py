@@ -610,8 +610,8 @@ def test_stream_priority_and_upload_overlap_do_not_change_results(monkeypatch):
     try:
         for prio in (-5, 7, 1, 0):
             h.set_option('stream_priority', prio)
-        monkeypatch.setenv('NBLS_UPLOAD_OVERLAP', '0')
-        monkeypatch.setenv('NBLS_GROUP_ORDER', '0')          # the groups' passes not ordered on the GPU either
+        monkeypatch.setattr(engine, 'UPLOAD_OVERLAP', False)
+        monkeypatch.setattr(engine, 'GROUP_ORDER', False)        # the groups' passes not ordered on the GPU either
         out = narrow_band_least_squares(*args, rij=c['rij'])
     finally:
         h.set_option('stream_priority', 0)

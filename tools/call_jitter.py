@@ -1,4 +1,4 @@
-"""Developer: per-call wall times of the whole cfg-3 call (jitter, warm-up drift); NBLS_PIPELINE_GROUPS / NBLS_PIPELINE_SPLIT
+"""Developer: per-call wall times of the whole cfg-3 call (jitter, warm-up drift); NBLS_PIPELINE_GROUPS / NBLS_STREAM_RESULTS
 from the environment."""
 import contextlib, io, os, sys, time
 sys.path.insert(0, '/root/repo')
@@ -22,5 +22,5 @@ for rep in range(30):
     ts.append((time.perf_counter() - t) * 1e3)
     del out
 print(' '.join('%.1f' % x for x in ts))
-print('stream=%s ' % os.environ.get('NBLS_STREAM_RESULTS', '1') + 'groups=%s split=%s: median %.2f  min %.2f  max %.2f ms' % (os.environ.get('NBLS_PIPELINE_GROUPS'), os.environ.get('NBLS_PIPELINE_SPLIT'),
+print('stream=%s ' % os.environ.get('NBLS_STREAM_RESULTS', '1') + 'groups=%s split=%s: median %.2f  min %.2f  max %.2f ms' % (os.environ.get('NBLS_PIPELINE_GROUPS'), engine.PIPELINE_SPLIT,
                                                                    np.median(ts[5:]), min(ts[5:]), max(ts[5:])))

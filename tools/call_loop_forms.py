@@ -14,21 +14,37 @@ def call():
         return narrow_band_least_squares(*args, rij=c['rij'])
 for _ in range(4):
     call()
-for form in ('held', 'dropped outside the clock', 'replaced by the next call'):
+import queue, threading
+for form in ('held', 'dropped outside the clock', 'replaced by the next call', 'handed to a consumer thread'):
     ts, held, out = [], [], None
+    q = queue.Queue()
+    def reaper():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            del item
+    th = threading.Thread(target=reaper)
+    th.start()
+    t_all = time.perf_counter()
     for rep in range(24):
         t = time.perf_counter()
         if form == 'held':
             held.append(call())
         elif form.startswith('dropped'):
             out = call()
+        elif form.startswith('handed'):
+            q.put(call())         # the consumer releases it while the next call waits for its GPU batches
         else:
             out = call()          # rebinding frees the previous result here, inside the clock
         ts.append((time.perf_counter() - t) * 1e3)
         if form.startswith('dropped'):
             out = None
+    q.put(None)
+    th.join()
+    t_all = (time.perf_counter() - t_all) / 24 * 1e3
     del held
-    print('%-28s median %.2f  min %.2f  max %.2f ms' % (form, np.median(ts[4:]), min(ts[4:]), max(ts[4:])))
+    print('%-28s median %.2f  min %.2f  max %.2f ms; loop mean incl. everything %.2f ms' % (form, np.median(ts[4:]), min(ts[4:]), max(ts[4:]), t_all))
 # what the teardown of ONE result costs, piece by piece
 import gc
 out = call()

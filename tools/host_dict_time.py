@@ -30,7 +30,7 @@ for rep in range(6):
     del d, keys
     for nt in (1, 2, 4, 8):
         import os
-        os.environ['NBLS_KEY_THREADS'] = str(nt)
+        engine.KEY_THREADS = nt
         t0 = time.perf_counter()
         kt = engine.time_key_text(t, nwin, pref)
         t1 = time.perf_counter()
