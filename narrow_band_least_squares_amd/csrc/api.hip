@@ -743,6 +743,9 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     // written for every computed window and read for no other — the rows nobody computed are zeroed on the host by the
     // rare caller that fetches them (nbls_fetch: zero_uncomputed)
     (void)cells; (void)P;
+    // (a caller that did not wait for every streamed batch of the previous pass: its copies still read the block)
+    if (!h->rbatches.empty() && h->cstream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->rev[2 * (h->rbatches.size() - 1) + 1], 0));
+    h->rbatches.clear();
     HIPCHK(h, hipMemsetAsync(h->d_res, 0, h->res_bytes, h->stream));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
@@ -761,9 +764,6 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
         if (g.u1 > g.u0) nbatch_est += g.screen && h->screen_batch > 0 ? (g.u1 - g.u0 + h->screen_batch - 1) / h->screen_batch : 1;
     const bool small_batches = nbatch_est > 1 && h->nunits / nbatch_est < 1024;
     h->solve_on_stream2 = h->fuse_solve && h->stream2 && (h->opt.overlap > 0 || (h->opt.overlap == 0 && h->stream_results && small_batches));
-    // (a caller that did not wait for every batch of the previous pass: its copies read the block this pass clears)
-    if (!h->rbatches.empty() && h->cstream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->rev[2 * (h->rbatches.size() - 1) + 1], 0));
-    h->rbatches.clear();
     if (h->stream_results) {
         if (!h->cstream) HIPCHK(h, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
         if (h->cap_hres < h->res_bytes) {
