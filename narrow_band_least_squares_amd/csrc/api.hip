@@ -1084,6 +1084,8 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_tb4", &nbls_options::screen_tb4, false},
         {"screen_pretest", &nbls_options::screen_pretest, false},
         {"screen_tb8", &nbls_options::screen_tb8, false},
+        {"screen_cxx", &nbls_options::screen_cxx, false},
+        {"screen_nc4", &nbls_options::screen_nc4, false},
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"solve_min_units", &nbls_options::solve_min_units, false},

@@ -31,6 +31,8 @@ struct nbls_options {
     int screen_tb4 = 0;        // 1: four-tile lag groups also where the eight-tile instance of the screening kernel applies
     int screen_static = 0;     // 1: fixed (snake-order) deal of the lag groups instead of the dynamic one
     int screen_pretest = 0;    // 1: integer pre-test of a lag group's accumulators before the f32 conversion (epilogue)
+    int screen_cxx = 0;        // 1: the compiler-scheduled K loop of the screening kernel everywhere (experiment)
+    int screen_nc4 = 0;        // 1: four byte-shifted copies per sliding channel also where eight fit (experiment)
     int screen_tb8 = 0;        // 1: the eight-tile instance wherever one lag block per tile step applies (S == 1)
     int screen_batch_mb = 192;  // quantised-window bytes per unit batch
     int solve_min_units = 0;   // > 0: units a per-batch solve (and a streamed result batch) covers at least (default 8192)

@@ -71,6 +71,7 @@ struct QArgs {
     int Wuni;                 // the window length when all bands share it (saves two dependent loads), else 0
     int tab_lds;              // energy tables of the pruning test staged in LDS (else read from qmeta when needed)
     unsigned int tab_inv;     // ceil(2^32 / (WP/32 + 2)): division of a table index by the row length as one v_mul_hi
+    int cxx;                  // experiment (option "screen_cxx"): the compiler-scheduled K loop also where a hand-scheduled one exists
     int seed;                 // developer experiment: running maxima seeded from the previous pass's candidate records
     int pretest;              // epilogue: integer pre-test on the accumulators before they are converted (option "screen_pretest")
     int dyn;                  // lag groups dealt dynamically to the waves of a sliding channel (else fixed snake order)
@@ -389,7 +390,7 @@ constexpr int TB = 4;            // tile steps processed together (they share th
 
 // Fragment of the FOUR-copy layout (long windows, QArgs.ncopy == 4): 16 bytes at a 4-byte aligned LDS address.
 __device__ inline __attribute__((ext_vector_type(4))) int ld_frag32(const unsigned char* p) {
-    typedef const volatile int __attribute__((address_space(3))) * lds_i;
+    typedef const int __attribute__((address_space(3))) * lds_i;     // (not volatile: pairs may become ds_read2_b32)
     const lds_i q = (lds_i)p;
     typedef int v4i_ __attribute__((ext_vector_type(4)));
     return (v4i_){q[0], q[1], q[2], q[3]};
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(512, TBV == 8 ? 2 : 4) void screen_kernel(QArgs a) 
         if (!(NBLS_ABL(1))) {
         // the partner fragments of the NEXT K step are fetched while this step's products run
         v4i bh = *(const v4i*)(pBh), bl = *(const v4i*)(pBl);
-        if (step == 32 && NC == 8) {
+        if (step == 32 && NC == 8 && !a.cxx) {
             // Two lag blocks per tile step (5..8 partners): hand-scheduled K loop, see screen_kloop.inc (generated by
             // tools/gen_screen_kloop.py).  Tile t+2 at K step n and tile t at K step n+1 read the SAME A fragment, so
             // the A stream is walked once and every fragment pair is multiplied by two partner fragments; nothing is
@@ -1470,7 +1471,7 @@ bool nbls_screen_geometry(const nbls_handle* h, int maxW, int* S, int* PFB, int*
     // reads per fragment, hand-scheduled K loops); where not even two partners fit beside them (~7900 samples) FOUR copies
     // with dword-granular addressing on top (8 bytes per sample, four 4-byte reads per fragment, the C++ K loop): ~13 000
     // samples — example.py's WINLEN_1 = 60 s at 200 Hz
-    for (int nc = 8; nc >= 4; nc -= 4) {
+    for (int nc = h->opt.screen_nc4 ? 4 : 8; nc >= 4; nc -= 4) {        // (option screen_nc4: the four-copy layout also where eight fit — experiment)
         *ncopy = nc;
         for (int g = NPc; g >= 2; --g) {
             if (nc == 4 && g == 16) continue;            // (S == 1 selects the eight-tile instance, built for eight copies)
@@ -1540,6 +1541,7 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
     a.dyn = h->opt.screen_static ? 0 : 1;
     a.pretest = h->opt.screen_pretest ? 1 : 0;
     a.seed = h->opt.screen_seed ? 1 : 0;
+    a.cxx = h->opt.screen_cxx ? 1 : 0;
     {
         const unsigned long long d = (unsigned long long)(a.WP / 32 + 2);      // exact for every index below 2^32 / d
         a.tab_inv = (unsigned int)(((1ull << 32) + d - 1) / d);
