@@ -73,6 +73,23 @@ def test_c_abi_exports_every_declared_symbol():
     assert _hip.load_library().nbls_version() >= 100
 
 
+def test_transport_library_is_named_by_a_call_not_by_the_environment(monkeypatch):
+    """the shipped library read two test hooks from the environment (NBLS_RCCL_LIB, NBLS_ALLOW_SHARED_DEVICE).
+    Now the stand-in transport of the one-GPU rehearsals is named with nbls_comm_set_library: a path that does not
+    exist makes the next comm call fail with NBLS_ERR_COMM (nothing else is tried), the environment variable is
+    ignored, and NULL restores RCCL by its usual names."""
+    import ctypes as C
+    from narrow_band_least_squares_amd import _hip
+    lib = _hip.load_library()
+    monkeypatch.setenv('NBLS_RCCL_LIB', '/nonexistent/from_the_environment.so')
+    assert lib.nbls_comm_set_library(b'/nonexistent/libnot_rccl.so', 1) == 0
+    buf = (C.c_char * 128)()
+    assert lib.nbls_comm_unique_id(buf, 128) == _hip.NBLS_ERR_COMM
+    assert lib.nbls_comm_set_library(None, 0) == 0
+    src = open(os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'comm.hip')).read()
+    assert 'getenv' not in src and 'getenv' not in open(os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc', 'api.hip')).read()
+
+
 def test_fails_loudly_without_gpu_or_library(tmp_path):
     with pytest.raises(ImportError):
         _hip.load_library(str(tmp_path / 'nope.so'))
