@@ -487,7 +487,12 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     const auto tp0 = std::chrono::steady_clock::now();
     const int D = 2 * nsections;
     const int GG = NBLS_FILTER_GROUP;
-    std::vector<double> M((size_t)nbands * (GG + 1) * D * D), FW((size_t)nbands * NBLS_FILTER_CHUNK * D);
+    // (host tables kept in the handle between plans: a fresh 1.2 MB per plan is 300 page faults on the table threads, on the
+    //  critical path of every call — and trimmed back to the OS when it is freed)
+    std::vector<double>& M = h->hp_M;
+    std::vector<double>& FW = h->hp_FW;
+    M.resize((size_t)nbands * (GG + 1) * D * D);
+    FW.resize((size_t)nbands * NBLS_FILTER_CHUNK * D);
     {
         // long-double table arithmetic, 30-100 us per band: the bands are dealt to a few host threads (the
         // plan sits on the critical path of a call: the GPU has nothing to do until it is through)
@@ -582,12 +587,14 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
     if ((rc = alloc_copy(h, &h->d_nwin, h->nwin.data(), (size_t)nbands))) return rc;
     if ((rc = alloc_copy(h, &h->d_unit_off, h->unit_off.data(), (size_t)nbands + 1))) return rc;
     if ((rc = alloc_copy(h, &h->d_win_off, woff.data(), (size_t)nbands))) return rc;
-    std::vector<int32_t> ub((size_t)U);
+    std::vector<int32_t>& ub = h->hp_ub;
+    ub.resize((size_t)U);
     for (int b = 0; b < nbands; ++b)
         for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) ub[(size_t)u] = b;
     if ((rc = alloc_copy(h, &h->d_unit_band, ub.data(), (size_t)U))) return rc;
     {
-        std::vector<int32_t> uw((size_t)(U > 0 ? U : 1));
+        std::vector<int32_t>& uw = h->hp_uw;
+        uw.resize((size_t)(U > 0 ? U : 1));
         for (int b = 0; b < nbands; ++b)
             for (int64_t u = h->unit_off[b]; u < h->unit_off[b + 1]; ++u) uw[(size_t)u] = (int32_t)(u - h->unit_off[b]) + woff[b];
         if ((rc = alloc_copy(h, &h->d_unit_win, uw.data(), (size_t)U))) return rc;

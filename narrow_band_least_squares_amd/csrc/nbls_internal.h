@@ -177,6 +177,8 @@ struct nbls_handle {
     // nbls_plan's tables live in ONE device arena at the offsets they have in the staging arena and go up in ONE copy
     // when the plan returns (a plan is ~25 tables; each HIP call of a plan that runs beside the trace upload of a
     // pipelined call's first group waited for the runtime's lock: 0.8 instead of 0.4 ms before the first launch)
+    std::vector<double> hp_M, hp_FW;       // host side of the plan's filter tables, kept between plans (no allocation per call)
+    std::vector<int32_t> hp_ub, hp_uw;     // ... and of the unit -> (band, window) tables
     std::vector<int32_t> woff;     // first computed window of every band of the plan (0 unless window-sharded)
     bool work_queued = false;      // kernels that read the plan / geometry tables may still be queued (set by nbls_execute*, cleared by
                                    // the calls that wait for the handle's stream): a plan has to order its uploads behind them only then
