@@ -240,14 +240,15 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         if err:
             raise err[0]
 
-    # One process drives every GPU and the shares are contiguous band ranges: every pass also STREAMS its rows to the host
-    # (nbls_stream_results), and the dropped-element dictionary — one entry per window, ~130 ns each under the GIL: 6.5 ms at
-    # the benchmark's shape, more than an eighth of a GPU pass — is built rank by rank (= band by band) while the GPUs
-    # are still working.  The grids still arrive through the ONE RCCL gather below.
+    # The shares are contiguous band ranges: every LOCAL pass also STREAMS its rows to the host (nbls_stream_results), and
+    # the dropped-element dictionary — one entry per window, ~130 ns each under the GIL: 6.5 ms at the benchmark's shape,
+    # more than an eighth of a GPU pass — is built for the local ranks (= band ranges) while the GPUs are still working:
+    # all of it when one process drives every GPU, this rank's 1/world of it under a launcher (the other ranks' entries
+    # are made after the gather, from the gathered masks).  The grids still arrive through the ONE RCCL gather below.
     use_stream = False
     if status == 0:
         cap = max(1, engine.max_bands_per_pass(nchans, npts))      # filtered bands one pass may keep in HBM
-        use_stream = (not by_windows and ALPHA < 1.0 and contiguous and group.root == 0 and len(group.handles) == world
+        use_stream = (not by_windows and ALPHA < 1.0 and contiguous
                       and engine.streamed_default() and max(len(sh) for sh in shards) <= cap
                       and all(hasattr(hd, 'wait_result_batch') for hd in group.handles))
 
@@ -297,17 +298,26 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         except Exception as e:
             status, failure = 1, e
 
-    stdict_streamed = None
+    stdict_head, stdict_parts, cum, cache = None, {}, None, None
     if use_stream and status == 0:
-        # rank order = band order: rank 0's batches first (the later ranks' rows wait in their pinned mirrors meanwhile)
+        # rank order = band order: the lowest local rank's batches first (the later ranks' rows wait in their pinned mirrors
+        # meanwhile).  Local ranks 0, 1, … (a prefix of the rank order) write straight into the final dictionary; a local rank
+        # behind a remote one fills a dictionary of its own, merged in rank order after the gather
         try:
             MBs = prep.mask_bytes
             cum = np.concatenate(([0], np.cumsum(prep.nwin))).astype(np.int64)
             smask = np.zeros((NBANDS, vector_len, MBs), dtype=np.uint8)
-            stdict_streamed = engine.new_stdict(engine.n_keys(keys))
+            stdict_head = engine.new_stdict(engine.n_keys(keys))
             cache = engine.new_pattern_cache()
-            for i, hd in enumerate(group.handles):
-                sh = shards[group.ranks[i]]
+            order = sorted(range(len(group.handles)), key=lambda i: group.ranks[i])
+            for n, i in enumerate(order):
+                r, hd = group.ranks[i], group.handles[i]
+                if r == n:
+                    target = stdict_head
+                else:
+                    target = stdict_parts[r] = engine.new_stdict(int(cum[shards[r][-1] + 1] - cum[shards[r][0]]) if shards[r] else 0)
+                stdict_parts.setdefault(r, None)
+                sh = shards[r]
                 if not sh:
                     continue
                 b0, b1 = sh[0], sh[-1] + 1
@@ -316,13 +326,10 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
                     if c1 > c0:
                         smask[b0:b1].reshape(-1, MBs)[c0:c1] = msrc[c0:c1]
                     if u1 > u0:
-                        engine.stdict_from_mask(smask, prep.nwin, prep.pair_idx, nchans, keys, into=stdict_streamed, cache=cache,
+                        engine.stdict_from_mask(smask, prep.nwin, prep.pair_idx, nchans, keys, into=target, cache=cache,
                                                 units=(int(cum[b0]) + u0, int(cum[b0]) + u1))
-            if 'size' not in stdict_streamed:
-                stdict_streamed['size'] = nchans
-            engine.release_later(cache)
         except Exception as e:      # noqa: BLE001 - reported through the gather's status word like every other local failure
-            status, failure, stdict_streamed = 1, e, None
+            status, failure, stdict_head, stdict_parts = 1, e, None, {}
 
     blocks = group.gather(block_bytes, status)          # the ONE collective
     if failure is not None:
@@ -354,6 +361,21 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
         stdict_all = None
         sig_tau_array = grids[3]
     else:
-        stdict_all = stdict_streamed if stdict_streamed is not None else engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys)
+        if stdict_head is None:
+            stdict_all = engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys)
+        else:
+            # rank order = band order = the order of the reference's dictionary: what a local rank streamed is there already,
+            # the rest comes from the gathered masks
+            stdict_all = stdict_head
+            for r in range(world):
+                if r not in stdict_parts:
+                    if shards[r]:
+                        engine.stdict_from_mask(mask, prep.nwin, prep.pair_idx, nchans, keys, into=stdict_all, cache=cache,
+                                                units=(int(cum[shards[r][0]]), int(cum[shards[r][-1] + 1])))
+                elif stdict_parts[r] is not None:
+                    stdict_all.update(stdict_parts[r])
+            if 'size' not in stdict_all:
+                stdict_all['size'] = nchans
+            engine.release_later(cache)
         sig_tau_array = np.zeros((NBANDS, vector_len))
     return (grids[0], grids[1], grids[2], t_array, stdict_all, sig_tau_array, num_compute_list, w_array, h_array)

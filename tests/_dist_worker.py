@@ -50,7 +50,7 @@ class FakeHandle:
         self.block = np.array(block, dtype=np.uint8)
         self.loaded = True
 
-    # streamed passes (the one-process form with contiguous shares): the block arrives in batches that cut through bands
+    # streamed passes (contiguous band shares): the block arrives in batches that cut through bands
     streamed = False
     waited = 0
 
@@ -231,6 +231,11 @@ def main():
             raise RuntimeError('injected failure before planning on rank 1')
         group.handles[0].set_trace_shape = boom
     nb = call_and_compare(gold, group, expect_failure=mode in ('fail', 'fail_early'))
+    if mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS', '1') != '0':
+        # under a launcher too, a rank builds the dictionary entries of ITS bands from its streamed batches (rank 0 straight
+        # into the result, rank 1 into a part merged behind rank 0's gathered entries); the key order is checked above
+        hd = group.handles[0]
+        assert hd.block is None or (hd.streamed and hd.waited == hd.result_batches() > 0), 'rank %d did not stream' % rank
     td.barrier()
     if rank == 0:
         print('DIST_OK world=%d bands=%d mode=%s' % (world, nb, mode))

@@ -3,12 +3,19 @@
 dictionary, 7.5 ms at cfg-3; r04: the dictionary is built from the ranks' streamed batches while the GPUs work.)  The
 GPU times mean nothing here (N ranks share one GPU); the host terms do.
 
-    python tools/sharded_rehearsal.py [nranks=8] [cfg3]            NBLS_STREAM_RESULTS=0: the r03 behaviour"""
+    python tools/sharded_rehearsal.py [nranks=8] [cfg3]            NBLS_STREAM_RESULTS=0: the r03 behaviour
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_rehearsal.py N
+        the launcher form (one process per rank, all on GPU 0): every rank streams ITS share's entries, the others' follow the gather"""
 import contextlib, io, os, sys, time
 ROOT = __file__.rsplit('/', 2)[0]
 sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-os.environ['NBLS_DEVICES'] = ','.join(['0'] * n)
+launcher = int(os.environ.get('WORLD_SIZE', '1')) > 1       # python -m torch.distributed.run --nproc-per-node N tools/sharded_rehearsal.py N
+if launcher:
+    n = int(os.environ['WORLD_SIZE'])
+    os.environ['NBLS_DEVICE'] = '0'
+else:
+    os.environ['NBLS_DEVICES'] = ','.join(['0'] * n)
 os.environ['NBLS_FORCE_DIST_PATH'] = '1'
 import numpy as np
 from narrow_band_least_squares_amd import dist, engine, planner, synthetic, narrow_band_least_squares_parallel, narrow_band_least_squares
@@ -37,5 +44,5 @@ with contextlib.redirect_stdout(io.StringIO()):
 for i in (0, 1, 2, 3, 5, 7, 8):
     assert np.array_equal(out[i], ser[i])
 assert list(out[4].keys()) == list(ser[4].keys())
-print('%d ranks on one GPU, stream=%s: whole call median %.2f ms; until the gather is entered %.2f ms; AFTER the gather has delivered %.2f ms (dictionary: %d entries); equal to the serial call'
-      % (n, os.environ.get('NBLS_STREAM_RESULTS', '1'), np.median(tot[3:]), np.median(pre[3:]), np.median(post[3:]), len(out[4])))
+print('%s%d ranks on one GPU, stream=%s: whole call median %.2f ms; until the gather is entered %.2f ms; AFTER the gather has delivered %.2f ms (dictionary: %d entries); equal to the serial call'
+      % ('launcher form, rank %s of ' % os.environ['RANK'] if launcher else '', n, os.environ.get('NBLS_STREAM_RESULTS', '1'), np.median(tot[3:]), np.median(pre[3:]), np.median(post[3:]), len(out[4])))
