@@ -12,10 +12,11 @@ from .lts_array import ltsva
 from .helpers import (get_freqlist, get_winlenlist, filter_data, make_float, get_rij,
                       write_txtfile, read_txtfile)
 from .stream import Stream, Trace, Stats
+from .engine import resident_trace
 
 __all__ = ['narrow_band_least_squares', 'narrow_band_loop', 'narrow_band_least_squares_parallel',
            'ltsva', 'get_freqlist', 'get_winlenlist', 'filter_data', 'make_float', 'get_rij',
-           'write_txtfile', 'read_txtfile', 'Stream', 'Trace', 'Stats', 'install_as_reference_modules']
+           'write_txtfile', 'read_txtfile', 'Stream', 'Trace', 'Stats', 'install_as_reference_modules', 'resident_trace']
 
 
 def install_as_reference_modules():

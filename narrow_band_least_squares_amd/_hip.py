@@ -157,6 +157,7 @@ class Handle:
         self.nbands = self.vector_len = 0
         self._keep = []
         self.profiling = False
+        self.resident_key = None        # engine.resident_trace: what the trace in HBM was uploaded from (any new trace clears it)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -179,6 +180,7 @@ class Handle:
             raise NblsError(rc, msg)
 
     def set_trace(self, data, fs):
+        self.resident_key = None
         data = _f64(data)
         if data.ndim != 2:
             raise ValueError('trace must be (nchans, npts)')
@@ -188,6 +190,7 @@ class Handle:
     def set_trace_rows(self, rows, fs):
         """rows: one 1-D float64 C-contiguous array per channel, all of the same length (uploaded
         straight from where they are: no packed host copy)."""
+        self.resident_key = None
         npts = len(rows[0])
         keep = []
         for r in rows:
@@ -203,11 +206,13 @@ class Handle:
 
     def set_trace_shape(self, nchans, npts, fs):
         """Declare the trace (no samples yet): geometry and plan may follow while ``upload_rows`` runs on another thread."""
+        self.resident_key = None
         self._chk(self.lib.nbls_set_trace_shape(self._h, int(nchans), int(npts), float(fs)))
         self.nchans, self.npts, self.fs = int(nchans), int(npts), float(fs)
 
     def upload_rows(self, rows):
         """The samples of the declared trace: one 1-D float64 C-contiguous array per channel."""
+        self.resident_key = None
         keep = []
         for r in rows:
             r = np.asarray(r)
@@ -223,6 +228,7 @@ class Handle:
 
     def set_trace_from(self, other):
         """The trace of another handle on the same GPU, copied device-to-device."""
+        self.resident_key = None
         self._chk(self.lib.nbls_set_trace_from(self._h, other._h))
         self.nchans, self.npts, self.fs = other.nchans, other.npts, other.fs
 

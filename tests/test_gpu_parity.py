@@ -382,6 +382,54 @@ def test_two_raw_maxima_that_share_one_quotient_go_to_the_earlier_lag(oracle, sw
         np.testing.assert_allclose(res.cmax[0, :1], internals['cmax'].T, rtol=1e-12)
 
 
+def test_resident_trace_skips_the_upload_and_changes_nothing(monkeypatch):
+    """``with engine.resident_trace(st)``: the samples go up once; calls on the same buffers inside the block skip their
+    upload (counted here on the handle), give the results of ordinary calls bit for bit — several parameter sets, the
+    band-group form of rounds 2-3 included — and a different trace in between ends the residency instead of being
+    processed on the old samples."""
+    from narrow_band_least_squares_amd import resident_trace
+    c = _cfg('cfg2', 0.25)
+    fr = np.logspace(-2, 1, 24)
+    w = np.zeros(24)
+
+    def args(nb, alpha, st):
+        return (c['WINLEN_list'][:nb], 0.5, alpha, st, None, None, nb, w, w, c['freqlist'][:nb + 1], 'log', fr, 'butter', 2, 0.01)
+
+    def same(a, b):
+        for i in (0, 1, 2, 3, 5, 7, 8):
+            np.testing.assert_array_equal(a[i], b[i])
+        assert a[6] == b[6]
+        if a[4] is None:
+            assert b[4] is None
+        else:
+            assert list(a[4].keys()) == list(b[4].keys())
+            for k in a[4]:
+                np.testing.assert_array_equal(a[4][k], b[4][k])
+
+    plain = {(nb, al): narrow_band_least_squares(*args(nb, al, c['st']), rij=c['rij']) for nb, al in ((6, 0.5), (9, 1.0))}
+    h = engine.get_handle()
+    uploads = []
+    for name in ('upload_rows', 'set_trace_rows', 'set_trace'):
+        real = getattr(h, name)
+        monkeypatch.setattr(h, name, lambda *a, _r=real, _n=name, **k: (uploads.append(_n), _r(*a, **k))[1])
+    with resident_trace(c['st']):
+        assert len(uploads) == 1
+        for key in plain:
+            same(narrow_band_least_squares(*args(*key, c['st']), rij=c['rij']), plain[key])
+        monkeypatch.setenv('NBLS_PIPELINE_GROUPS', '3')
+        same(narrow_band_least_squares(*args(6, 0.5, c['st']), rij=c['rij']), plain[(6, 0.5)])
+        monkeypatch.delenv('NBLS_PIPELINE_GROUPS')
+        assert len(uploads) == 1, uploads
+        # another trace on the same GPU: processed from ITS samples, and the first one has to go up again afterwards
+        other = synthetic.make_stream(np.array([tr.data for tr in c['st']])[:, ::-1].copy(), c['fs'], starttime=c['st'][0].stats.starttime)
+        rev = narrow_band_least_squares(*args(6, 0.5, other), rij=c['rij'])
+        assert len(uploads) == 2 and not np.array_equal(rev[1], plain[(6, 0.5)][1])
+        same(narrow_band_least_squares(*args(6, 0.5, c['st']), rij=c['rij']), plain[(6, 0.5)])
+        assert len(uploads) == 3
+    same(narrow_band_least_squares(*args(6, 0.5, c['st']), rij=c['rij']), plain[(6, 0.5)])
+    assert len(uploads) == 4
+
+
 @pytest.mark.parametrize('alpha', [0.5, 1.0])
 def test_streamed_pass_equals_the_unstreamed_one(alpha, monkeypatch):
     """The default whole call since round 4 (nbls_stream_results): every unit batch a complete correlate -> solve -> pack

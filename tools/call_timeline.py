@@ -44,8 +44,11 @@ fr = np.logspace(-2, np.log10(c['fs'] / 2), 1000)
 w = np.zeros(1000)
 args = (c['WINLEN_list'], c['overlap'], c['alpha'], c['st'], None, None, c['NBANDS'], w, w, c['freqlist'],
         c['band_type'], fr, c['ftype'], c['order'], c['ripple'])
-HOLD = len(sys.argv) > 2 and sys.argv[2] == 'hold'     # keep every call's result alive (what bench.py's timed loop does)
+HOLD = 'hold' in sys.argv[2:]     # keep every call's result alive (what bench.py's timed loop does)
+RESIDENT = 'resident' in sys.argv[2:]     # the calls run inside `with engine.resident_trace(st)`: no upload
 kept = []
+ctx = engine.resident_trace(c['st']) if RESIDENT else contextlib.nullcontext()
+ctx.__enter__()
 for rep in range(12 if HOLD else 6):
     planner.design_cache_clear()
     events.clear()
@@ -56,6 +59,7 @@ for rep in range(12 if HOLD else 6):
     if HOLD:
         kept.append(out)
     del out
-print('whole call %.2f ms' % total)
+ctx.__exit__(None, None, None)
+print('whole call %.2f ms%s' % (total, ' (trace resident)' if RESIDENT else ''))
 for label, a, b in sorted(events, key=lambda e: e[1]):
     print('  %6.2f .. %6.2f  (%5.2f)  %s' % (a, b, b - a, label))
