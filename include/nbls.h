@@ -108,9 +108,18 @@ int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src);
  * nbls_set_trace_shape declares the trace (allocation and shape, no samples), after which nbls_set_geometry and
  * nbls_plan may be called; nbls_upload_rows copies the samples (returns when the rows may be reused) and MAY RUN ON
  * ANOTHER THREAD meanwhile — the one exception to "one handle, one thread at a time".  nbls_execute returns
- * NBLS_ERR_STATE until nbls_upload_rows has returned. */
+ * NBLS_ERR_STATE until nbls_upload_rows has returned — unless the upload was ANNOUNCED:
+ * nbls_expect_upload (after nbls_set_trace_shape, by the thread that goes on to plan and execute) says that
+ * nbls_upload_rows is about to run on another thread.  nbls_execute may then be called while the rows are still going
+ * up: the rows travel on a stream of their own with an event behind each, and a pass with a filter stage filters the
+ * channels as they land ((band, channel) series are independent: identical results) instead of starting after the last
+ * one — the copy of a long trace (16 elements x 24 h at 100 Hz: 1.1 GB, 20 ms over PCIe) hides the filter.  It waits on
+ * the host for each next row to be queued, and fails with NBLS_ERR_STATE if the upload fails, is aborted
+ * (nbls_abort_upload: the announcing side learned that the rows will not come) or does not start within 120 s. */
 int nbls_set_trace_shape(nbls_handle* h, int32_t nchans, int64_t npts, double fs);
 int nbls_upload_rows(nbls_handle* h, const double* const* rows, int32_t nchans, int64_t npts);
+int nbls_expect_upload(nbls_handle* h);
+int nbls_abort_upload(nbls_handle* h);
 
 /* Co-array: xij[npairs][2] (km; pair k = (i,j), i<j, lexicographic; xij = r_i - r_j),
  * pair_idx[npairs][2], xpinv[2][npairs] = pseudo-inverse of xij (OLS). */
@@ -288,8 +297,10 @@ int nbls_comm_destroy(nbls_handle* h);
  *   "lts_impl" 0 auto | 1 lane-per-start generic FAST-LTS kernel | 3 generic only where no register kernel exists;
  *   "lts_generic_h", "lts_coop_threads", "lts_sample_its", "screen_tb4", "screen_tb8", "screen_nsl1", "screen_static",
  *   "screen_pretest", "screen_batch_mb", "solve_min_units" (units a per-batch solve / streamed result batch covers at least),
+ *   "result_tail_units" (streamed pass: units of the last result batch, cut off the last solve; 0 = default 2048, < 0 = not cut),
  *   "overlap" (the solve of a unit batch on a second stream beside the next batch's correlation: 1 on, -1 off, 0 auto = on
- *   for streamed passes of several small batches), "filter_nofuse",
+ *   for streamed passes of several small batches), "filter_nofuse", "filter_row_step" (channels per filter launch: what a
+ *   pass queued on an announced upload does as the rows land, forced),
  *   "filter_nomfma";
  *   "stream_priority" (applied at once; the handle must be idle): 0 normal, > 0 lower, < 0 higher, clamped to the
  *   device's range — for several handles of one GPU whose passes run side by side.

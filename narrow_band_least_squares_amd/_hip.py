@@ -21,7 +21,7 @@ EXPORTS = [
     'nbls_comm_init_rank', 'nbls_reserve_results', 'nbls_comm_gather', 'nbls_comm_destroy', 'nbls_set_option',
     'nbls_developer_build', 'nbls_set_trace_from', 'nbls_debug_lts_coop_breakdown', 'nbls_filter_segment',
     'nbls_set_filtered', 'nbls_load_result_block', 'nbls_stream_results', 'nbls_result_batches', 'nbls_wait_result_batch',
-    'nbls_comm_set_library', 'nbls_set_uncertainty', 'nbls_fetch_uncertainty',
+    'nbls_comm_set_library', 'nbls_set_uncertainty', 'nbls_fetch_uncertainty', 'nbls_expect_upload', 'nbls_abort_upload',
 ]
 
 NBLS_ERR_ARG, NBLS_ERR_STATE, NBLS_ERR_GEOMETRY = -1, -2, -3
@@ -84,6 +84,8 @@ def load_library(path=None):
     lib.nbls_load_result_block.argtypes = [vp, C.c_void_p, C.c_int64]
     lib.nbls_comm_gather.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.nbls_comm_destroy.argtypes = [vp]
+    lib.nbls_expect_upload.argtypes = [vp]
+    lib.nbls_abort_upload.argtypes = [vp]
     lib.nbls_comm_set_library.argtypes = [C.c_char_p, C.c_int32]
     lib.nbls_set_uncertainty.argtypes = [vp, dp]
     lib.nbls_fetch_uncertainty.argtypes = [vp, dp, dp]
@@ -210,20 +212,29 @@ class Handle:
         self._chk(self.lib.nbls_set_trace_shape(self._h, int(nchans), int(npts), float(fs)))
         self.nchans, self.npts, self.fs = int(nchans), int(npts), float(fs)
 
+    def expect_upload(self):
+        """Announce (on the thread that goes on to plan and execute) that ``upload_rows`` is about to run on another
+        thread: ``execute`` may then be called while the rows are still going up, the pass filters them as they land."""
+        self._chk(self.lib.nbls_expect_upload(self._h))
+
     def upload_rows(self, rows):
         """The samples of the declared trace: one 1-D float64 C-contiguous array per channel."""
         self.resident_key = None
-        keep = []
-        for r in rows:
-            r = np.asarray(r)
-            if r.dtype != np.float64 or not r.flags.c_contiguous:
-                r = np.ascontiguousarray(r, dtype=np.float64)
-            if r.ndim != 1 or len(r) != self.npts:
-                raise ValueError('All traces must have the same number of samples.')
-            keep.append(r)
-        if len(keep) != self.nchans:
-            raise ValueError('upload_rows: %d rows for a trace declared with %d channels' % (len(keep), self.nchans))
-        ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
+        try:
+            keep = []
+            for r in rows:
+                r = np.asarray(r)
+                if r.dtype != np.float64 or not r.flags.c_contiguous:
+                    r = np.ascontiguousarray(r, dtype=np.float64)
+                if r.ndim != 1 or len(r) != self.npts:
+                    raise ValueError('All traces must have the same number of samples.')
+                keep.append(r)
+            if len(keep) != self.nchans:
+                raise ValueError('upload_rows: %d rows for a trace declared with %d channels' % (len(keep), self.nchans))
+            ptrs = (C.c_void_p * len(keep))(*[r.ctypes.data for r in keep])
+        except BaseException:
+            self.lib.nbls_abort_upload(self._h)        # (a pass that was queued on the announced rows fails instead of waiting)
+            raise
         self._chk(self.lib.nbls_upload_rows(self._h, ptrs, len(keep), self.npts))
 
     def set_trace_from(self, other):

@@ -7,8 +7,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace {
 
@@ -143,6 +146,76 @@ void wait_uploads(nbls_handle* h) {
     if (!h->up_pending || !h->ev_up) return;
     for (hipStream_t s : {h->stream, h->stream2})
         if (s && s != h->up) (void)hipStreamWaitEvent(s, h->ev_up, 0);
+}
+
+// A few host threads kept asleep between plans (filter tables: long-double arithmetic, 30-100 us per band, on the critical
+// path of every call — the GPU has nothing to do until the plan is through).  Starting a thread costs ~15 us, one after
+// the other on the planning thread: eleven of them were a third of the 0.5 ms the tables of 48 bands took.  One job at a
+// time; a second planner (the launch threads of a multi-GPU call plan side by side) computes its bands inline instead of
+// waiting.  The pool is never destroyed (threads asleep at exit are simply gone with the process) and is rebuilt in a
+// forked child, which inherits none of them.
+struct TablePool {
+    std::mutex m;
+    std::condition_variable go, done;
+    std::mutex busy;                       // held for the length of one job
+    const std::function<void(int)>* job = nullptr;
+    int njob = 0, left = 0;
+    unsigned long gen = 0;
+    int nthreads = 0;
+    pid_t pid = 0;
+    void worker(int t) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            {
+                std::unique_lock<std::mutex> l(m);
+                go.wait(l, [&] { return gen != seen; });
+                seen = gen;
+                if (t >= njob) continue;
+                f = job;
+            }
+            (*f)(t);
+            std::lock_guard<std::mutex> l(m);
+            if (--left == 0) done.notify_one();
+        }
+    }
+};
+TablePool* g_pool = nullptr;
+std::mutex g_pool_mu;
+
+// f(0) .. f(n-1), f(0) on the calling thread; returns false when the pool is taken (the caller then runs everything itself)
+bool pool_run(int n, const std::function<void(int)>& f) {
+    constexpr int kThreads = 12;
+    TablePool* p;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        if (!g_pool || g_pool->pid != getpid()) {
+            p = new TablePool;                       // (an inherited pool of the parent process is left alone)
+            p->pid = getpid();
+            p->nthreads = kThreads;
+            for (int t = 1; t < kThreads; ++t) std::thread(&TablePool::worker, p, t).detach();
+            g_pool = p;
+        }
+        p = g_pool;
+    }
+    if (n > p->nthreads) return false;
+    std::unique_lock<std::mutex> use(p->busy, std::try_to_lock);
+    if (!use.owns_lock()) return false;
+    if (n > 1) {
+        std::lock_guard<std::mutex> l(p->m);
+        p->job = &f;
+        p->njob = n;
+        p->left = n - 1;
+        ++p->gen;
+        p->go.notify_all();
+    }
+    f(0);
+    if (n > 1) {
+        std::unique_lock<std::mutex> l(p->m);
+        p->done.wait(l, [&] { return p->left == 0; });
+        p->job = nullptr;
+    }
+    return true;
 }
 
 void filter_tables(const double* sos, int S, int C, int G, double* fw, double* mpow) {
@@ -284,6 +357,9 @@ void nbls_destroy(nbls_handle* h) {
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->rev) (void)hipEventDestroy(e);
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->ustream) { (void)hipStreamSynchronize(h->ustream); (void)hipStreamDestroy(h->ustream); }
+    for (hipEvent_t e : h->uev) (void)hipEventDestroy(e);
+    if (h->ev_uprev) (void)hipEventDestroy(h->ev_uprev);
     if (h->h_res) (void)hipHostFree(h->h_res);
     if (h->ev_xd) (void)hipEventDestroy(h->ev_xd);
     if (h->ev_plan) (void)hipEventDestroy(h->ev_plan);
@@ -316,29 +392,75 @@ static int trace_shape_impl(nbls_handle* h, int32_t nchans, int64_t npts, double
     h->fs = fs;
     h->planned = false;
     h->trace_loaded = false;
+    h->rows_landed.store(0, std::memory_order_release);
+    h->upload_state.store(2, std::memory_order_release);
     return NBLS_OK;
 }
 
-// Copy the samples of a declared trace.  Touches only d_trace, the compute stream and (on failure) the error text:
-// nbls_upload_rows may therefore run beside nbls_set_geometry / nbls_plan of the same handle on another thread.
+// Copy the samples of a declared trace, row by row on the handle's upload stream, an event behind every row (a pass
+// queued meanwhile on another thread filters the rows as they land, see wait_rows).  Touches only d_trace, the upload
+// stream and (on failure) the error text: nbls_upload_rows may therefore run beside nbls_set_geometry / nbls_plan /
+// nbls_execute of the same handle on another thread.
 static int trace_copy_impl(nbls_handle* h, const double* const* rows, const double* flat) {
+    struct Guard {
+        nbls_handle* h; bool ok = false;
+        ~Guard() { h->upload_state.store(ok ? 0 : -1, std::memory_order_release); }
+    } guard{h};
+    h->rows_landed.store(0, std::memory_order_release);
+    h->upload_state.store(1, std::memory_order_release);
     HIPCHK(h, hipSetDevice(h->device));
     const int32_t nchans = h->nchans;
     const int64_t npts = h->npts, pad = h->npts_pad;
+    if (!h->ustream) HIPCHK(h, hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking));
+    if (!h->ev_uprev) HIPCHK(h, hipEventCreateWithFlags(&h->ev_uprev, hipEventDisableTiming));
+    while ((int)h->uev.size() < nchans) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->uev.push_back(e);
+    }
+    // behind whatever is still queued on the compute streams: an earlier pass may be reading the trace this one replaces
+    for (hipStream_t s : {h->stream, h->stream2}) {
+        if (!s) continue;
+        HIPCHK(h, hipEventRecord(h->ev_uprev, s));
+        HIPCHK(h, hipStreamWaitEvent(h->ustream, h->ev_uprev, 0));
+    }
     if (pad > npts)
-        HIPCHK(h, hipMemset2DAsync(h->d_trace + npts, pad * sizeof(double), 0, (pad - npts) * sizeof(double), nchans, h->stream));
+        HIPCHK(h, hipMemset2DAsync(h->d_trace + npts, pad * sizeof(double), 0, (pad - npts) * sizeof(double), nchans, h->ustream));
     if (flat) {
         HIPCHK(h, hipMemcpy2DAsync(h->d_trace, pad * sizeof(double), flat, npts * sizeof(double),
-                                   npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->stream));
+                                   npts * sizeof(double), nchans, hipMemcpyHostToDevice, h->ustream));
+        for (int c = 0; c < nchans; ++c) HIPCHK(h, hipEventRecord(h->uev[c], h->ustream));
+        h->rows_landed.store(nchans, std::memory_order_release);
     } else {
-        for (int c = 0; c < nchans; ++c)
-            HIPCHK(h, hipMemcpyAsync(h->d_trace + (size_t)c * pad, rows[c], npts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        for (int c = 0; c < nchans; ++c) {
+            HIPCHK(h, hipMemcpyAsync(h->d_trace + (size_t)c * pad, rows[c], npts * sizeof(double), hipMemcpyHostToDevice, h->ustream));
+            HIPCHK(h, hipEventRecord(h->uev[c], h->ustream));
+            h->rows_landed.store(c + 1, std::memory_order_release);
+        }
     }
     // the caller's buffers may be reused as soon as this returns (pageable sources are staged before
     // hipMemcpyAsync returns; pinned ones are still being read): wait for the copies
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->ustream));
     h->trace_loaded = true;
+    guard.ok = true;
     return NBLS_OK;
+}
+
+// Host side of the row pipeline: wait until more than `done` channels of the trace are in flight behind their events
+// (-> how many), the upload has failed (-> -1), nothing arrives (-> -2) or the shape was declared but no upload announced
+// (nbls_expect_upload) or started (-> -3).  With no upload under way every channel is there.
+static int wait_rows(nbls_handle* h, int done) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        const int st = h->upload_state.load(std::memory_order_acquire);
+        const int landed = h->rows_landed.load(std::memory_order_acquire);
+        if (st < 0) return -1;
+        if (st == 0) return h->trace_loaded ? h->nchans : -1;
+        if (st == 2) return -3;                  // declared, and nobody has announced the samples
+        if (landed > done) return landed;
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return -2;
+        std::this_thread::yield();
+    }
 }
 
 static int set_trace_impl(nbls_handle* h, const double* const* rows, const double* flat, int32_t nchans, int64_t npts,
@@ -362,6 +484,21 @@ int nbls_upload_rows(nbls_handle* h, const double* const* rows, int32_t nchans, 
     return trace_copy_impl(h, rows, nullptr);
 }
 
+int nbls_expect_upload(nbls_handle* h) {
+    if (!h) return NBLS_ERR_ARG;
+    int declared = 2;
+    if (!h->upload_state.compare_exchange_strong(declared, 3, std::memory_order_acq_rel))
+        return fail(h, NBLS_ERR_STATE, "nbls_expect_upload: no trace shape declared (nbls_set_trace_shape) or its samples are there already");
+    return NBLS_OK;
+}
+
+int nbls_abort_upload(nbls_handle* h) {
+    if (!h) return NBLS_ERR_ARG;
+    int st = h->upload_state.load(std::memory_order_acquire);
+    while ((st == 2 || st == 3) && !h->upload_state.compare_exchange_weak(st, -1, std::memory_order_acq_rel)) {}
+    return NBLS_OK;
+}
+
 int nbls_set_trace(nbls_handle* h, const double* trace, int32_t nchans, int64_t npts, double fs) {
     if (!h) return NBLS_ERR_ARG;
     if (!trace || nchans < 1 || npts < 1 || !(fs > 0.0)) return fail(h, NBLS_ERR_ARG, "nbls_set_trace: bad argument");
@@ -380,7 +517,15 @@ int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src) {
         HIPCHK(h, hipMalloc((void**)&h->d_trace, need));
         h->cap_trace = need;
     }
-    // the source's upload has completed (nbls_set_trace* return after it); ordered on THIS handle's stream
+    // the source's upload has completed (nbls_set_trace* return after it) or is still running on another thread
+    // (nbls_upload_rows): wait for its last row; the copy is ordered on THIS handle's stream
+    {
+        nbls_handle* s_ = const_cast<nbls_handle*>(src);
+        int landed = 0;
+        while (landed >= 0 && landed < src->nchans) landed = wait_rows(s_, landed);
+        if (landed < 0) return fail(h, NBLS_ERR_STATE, "nbls_set_trace_from: the source handle's trace did not arrive");
+        if (!src->uev.empty() && (int)src->uev.size() >= src->nchans) HIPCHK(h, hipStreamWaitEvent(h->stream, src->uev[src->nchans - 1], 0));
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_trace, src->d_trace, need, hipMemcpyDeviceToDevice, h->stream));
     if (h->nchans != src->nchans && h->d_xij) {
         (void)hipFree(h->d_xij); h->d_xij = nullptr;
@@ -393,6 +538,8 @@ int nbls_set_trace_from(nbls_handle* h, const nbls_handle* src) {
     h->fs = src->fs;
     h->planned = false;
     h->trace_loaded = true;               // (ordered on this handle's stream before its next pass)
+    h->rows_landed.store(h->nchans, std::memory_order_release);
+    h->upload_state.store(0, std::memory_order_release);
     return NBLS_OK;
 }
 
@@ -498,16 +645,16 @@ int nbls_plan(nbls_handle* h, int32_t nbands, const double* sos, int32_t nsectio
         // plan sits on the critical path of a call: the GPU has nothing to do until it is through)
         double* const fwp = FW.data();
         double* const mp = M.data();
-        const int nt = nsections > 0 ? std::max(1, std::min(12, nbands / 3)) : 0;     // ~3+ bands per thread (a thread costs ~15 us to start)
-        auto work = [&](int t) {
+        int nt = nsections > 0 ? std::max(1, std::min(12, nbands / 2)) : 0;     // 2+ bands per thread of the pool (TablePool)
+        const std::function<void(int)> work = [&](int t) {
             for (int b = t; b < nbands; b += nt)
                 filter_tables(sos + (size_t)b * nsections * 6, nsections, NBLS_FILTER_CHUNK, GG,
                               fwp + (size_t)b * NBLS_FILTER_CHUNK * D, mp + (size_t)b * (GG + 1) * D * D);
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        if (nt > 0) work(0);
-        for (auto& x : th) x.join();
+        if (nt > 0 && !pool_run(nt, work)) {       // the pool is busy with another handle's plan: all bands here
+            nt = 1;
+            work(0);
+        }
     }
     const auto tp1 = std::chrono::steady_clock::now();
 
@@ -739,7 +886,11 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     if (!h) return NBLS_ERR_ARG;
     if (!h->planned) return fail(h, NBLS_ERR_STATE, "nbls_execute: no plan");
     if ((stage_mask & 6) && !h->d_xij) return fail(h, NBLS_ERR_STATE, "nbls_execute: no geometry set");
-    if (!h->trace_loaded) return fail(h, NBLS_ERR_STATE, "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded");
+    // the samples: uploaded — or on their way (nbls_upload_rows on another thread): a pass with a filter stage then takes
+    // the channels as they land; any other pass needs them all before it is queued
+    const int upload_st = h->upload_state.load(std::memory_order_acquire);      // (read BEFORE trace_loaded: the upload thread sets that first)
+    if (!((stage_mask & 1) && (upload_st == 1 || upload_st == 3)) && !h->trace_loaded)
+        return fail(h, NBLS_ERR_STATE, "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     wait_uploads(h);
     h->work_queued = true;
@@ -755,7 +906,21 @@ int nbls_execute_stages(nbls_handle* h, int32_t stage_mask) {
     h->rbatches.clear();
     HIPCHK(h, hipMemsetAsync(h->d_res, 0, h->res_bytes, h->stream));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    if (stage_mask & 1) HIPCHK(h, nbls_launch_filter(h));
+    if (stage_mask & 1) {
+        // every (band, channel) series is filtered on its own: the channels that have landed so far, then the next ones
+        // as their events are recorded (one launch of all channels when the trace is there already)
+        for (int done = 0; done < h->nchans;) {
+            int landed = wait_rows(h, done);
+            if (landed < 0 || landed <= done)
+                return fail(h, NBLS_ERR_STATE, landed == -2 ? "nbls_execute: the announced trace did not arrive (no nbls_upload_rows within 120 s)"
+                                               : landed == -3 ? "nbls_execute: the trace was declared (nbls_set_trace_shape) but not uploaded"
+                                                              : "nbls_execute: the upload of the trace failed");
+            if (h->opt.filter_row_step > 0 && landed > done + h->opt.filter_row_step) landed = done + h->opt.filter_row_step;   // (A/B and tests)
+            if ((int)h->uev.size() >= landed) HIPCHK(h, hipStreamWaitEvent(h->stream, h->uev[landed - 1], 0));
+            HIPCHK(h, nbls_launch_filter(h, done, landed - done));
+            done = landed;
+        }
+    }
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     h->solve_done = false;
     h->last_stage_mask = stage_mask;
@@ -1096,6 +1261,8 @@ int nbls_set_option(nbls_handle* h, const char* key, int64_t value) {
         {"screen_batch_mb", &nbls_options::screen_batch_mb, false},
         {"overlap", &nbls_options::overlap, false},
         {"solve_min_units", &nbls_options::solve_min_units, false},
+        {"result_tail_units", &nbls_options::result_tail_units, false},
+        {"filter_row_step", &nbls_options::filter_row_step, false},
         {"filter_nofuse", &nbls_options::filter_nofuse, false},
         {"filter_nomfma", &nbls_options::filter_nomfma, false},
         {"ablate", &nbls_options::ablate, true},

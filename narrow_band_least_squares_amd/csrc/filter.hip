@@ -50,6 +50,8 @@ struct FilterArgs {
     double* gin;           // [ngroups][nseries][2S]   state entering each group
     int nchans;
     int nseries;
+    int ch0, nch;          // the channels [ch0, ch0 + nch) of every band are processed by this launch (nsub = nbands * nch series):
+    int nsub;              // a pass may run channel by channel while the trace is still going up (nbls_execute, row events)
     int64_t npts;
     int64_t nchunks;
     int ngroups;
@@ -68,13 +70,18 @@ struct FilterArgs {
     double* fin;           // [nseries][2S] state after the last (whole) chunk, else NULL
 };
 
+// series (band, channel) of the launch's ql-th series: all channels -> ql itself
+__device__ __forceinline__ int series_of(const FilterArgs& a, int ql) {
+    return a.nch == a.nchans ? ql : (ql / a.nch) * a.nchans + a.ch0 + ql % a.nch;
+}
+
 // ---- states: one wave per (series, chunk) ----
 template <int S>
 __global__ __launch_bounds__(256) void filter_state_kernel(FilterArgs a) {
     constexpr int D = 2 * S;
     const int lane = threadIdx.x & 63;
     const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int q = blockIdx.y;
+    const int q = series_of(a, blockIdx.y);
     if (chunk >= a.nchunks) return;
     const int band = q / a.nchans;
     const double* in = a.in + (int64_t)(q % a.in_mod) * a.in_stride;
@@ -126,14 +133,14 @@ __global__ __launch_bounds__(256) void filter_state_mfma_kernel(FilterArgs a, in
     }
     __syncthreads();
     const int tpc = (int)((a.nchunks + 15) / 16);   // column tiles per channel
-    const int ntile = a.nchans * tpc;
+    const int ntile = a.nch * tpc;
     const int i = lane & 15, k = lane >> 4;
     // The sum over the samples may run in any order as long as both operands agree on it: K slot k of
     // step (m, u) stands for sample 16 m + 4 k + u, so that a lane fetches 32 contiguous bytes of its
     // chunk per four steps (whole 128-byte lines per wave) instead of 8 bytes per step.
     const double* wrow = wts + i * P + 4 * k;
     for (int ct = blockIdx.y * 4 + wv; ct < ntile; ct += gridDim.y * 4) {
-        const int ch = ct / tpc;
+        const int ch = a.ch0 + ct / tpc;
         const int64_t chunk = (int64_t)(ct % tpc) * 16 + i;          // this lane's column (B operand)
         const double* x = a.in + (int64_t)ch * a.in_stride + chunk * C + 4 * k;
         const int64_t left = chunk < a.nchunks ? a.npts - (chunk * C + 4 * k) : 0;   // valid samples from x[0]
@@ -176,9 +183,10 @@ __global__ __launch_bounds__(256) void filter_state_mfma_kernel(FilterArgs a, in
 template <int S>
 __global__ void filter_carry_local_kernel(FilterArgs a) {
     constexpr int D = 2 * S;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ql = blockIdx.x * blockDim.x + threadIdx.x;
     const int gi = blockIdx.y;
-    if (q >= a.nseries) return;
+    if (ql >= a.nsub) return;
+    const int q = series_of(a, ql);
     const int band = q / a.nchans;
     const double* M = a.mpow + ((int64_t)band * (G + 1) + 1) * D * D;      // M^1
     double m[D][D], s[D];
@@ -216,8 +224,9 @@ __global__ void filter_carry_local_kernel(FilterArgs a) {
 template <int S>
 __global__ void filter_carry_groups_kernel(FilterArgs a) {
     constexpr int D = 2 * S;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= a.nseries) return;
+    const int ql = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ql >= a.nsub) return;
+    const int q = series_of(a, ql);
     const int band = q / a.nchans;
     double s[D];
 #pragma unroll
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(64) void filter_apply_kernel(FilterArgs a) {
     __shared__ double tile[64][T + 1];
     __shared__ double wtile[T * D];      // backward-pass state weights of the tile's samples (fused states)
     const int lane = threadIdx.x;
-    const int q = blockIdx.y;
+    const int q = series_of(a, blockIdx.y);
     const int band = q / a.nchans;
     const int64_t chunk0 = (int64_t)blockIdx.x * 64;
     const int64_t chunk = chunk0 + lane;
@@ -432,7 +441,7 @@ hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
         const size_t shm = (size_t)16 * (C + 4) * sizeof(double);
         hipError_t e = hipFuncSetAttribute((const void*)filter_state_mfma_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
-        const int tiles = a.nchans * (int)((a.nchunks + 15) / 16);
+        const int tiles = a.nch * (int)((a.nchunks + 15) / 16);
         // column tiles per wave chosen so that the grid is about one round of two workgroups per CU
         int per_wave = (rows * tiles + 4 * 512 - 1) / (4 * 512);
         if (per_wave < 1) per_wave = 1;
@@ -440,12 +449,12 @@ hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
         if (splits < 1) splits = 1;
         hipLaunchKernelGGL((filter_state_mfma_kernel<S>), dim3((unsigned)rows, (unsigned)splits), dim3(256), shm, h->stream, a, nbands);
     } else if (!states_ready)
-        hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nseries),
+        hipLaunchKernelGGL((filter_state_kernel<S>), dim3((unsigned)((h->nchunks + 3) / 4), (unsigned)a.nsub),
                            dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nseries + 63) / 64, a.ngroups), dim3(64), 0,
+    hipLaunchKernelGGL((filter_carry_local_kernel<S>), dim3((a.nsub + 63) / 64, a.ngroups), dim3(64), 0,
                        h->stream, a);
-    hipLaunchKernelGGL((filter_carry_groups_kernel<S>), dim3((a.nseries + 63) / 64), dim3(64), 0, h->stream, a);
-    const dim3 agrid((unsigned)((h->nchunks + 63) / 64), (unsigned)a.nseries);
+    hipLaunchKernelGGL((filter_carry_groups_kernel<S>), dim3((a.nsub + 63) / 64), dim3(64), 0, h->stream, a);
+    const dim3 agrid((unsigned)((h->nchunks + 63) / 64), (unsigned)a.nsub);
     if (a.recompute == 1) hipLaunchKernelGGL((filter_apply_kernel<S, 1>), agrid, dim3(64), 0, h->stream, a);
     else if (a.recompute == 2) hipLaunchKernelGGL((filter_apply_kernel<S, 2>), agrid, dim3(64), 0, h->stream, a);
     else hipLaunchKernelGGL((filter_apply_kernel<S, 0>), agrid, dim3(64), 0, h->stream, a);
@@ -453,10 +462,13 @@ hipError_t run_pass(nbls_handle* h, const FilterArgs& a, bool states_ready) {
 }
 
 template <int S>
-hipError_t run_filter(nbls_handle* h) {
+hipError_t run_filter(nbls_handle* h, int ch0, int nch) {
     FilterArgs a;
     a.nchans = h->nchans;
     a.nseries = h->nbands * h->nchans;
+    a.ch0 = ch0;
+    a.nch = nch;
+    a.nsub = h->nbands * nch;
     a.npts = h->npts;
     a.nchunks = h->nchunks;
     a.ngroups = (int)((h->nchunks + G - 1) / G);
@@ -518,6 +530,9 @@ hipError_t run_filter_segment(nbls_handle* h, int reverse, const double* d_init,
     FilterArgs a;
     a.nchans = h->nchans;
     a.nseries = h->nbands * h->nchans;
+    a.ch0 = 0;
+    a.nch = h->nchans;
+    a.nsub = a.nseries;
     a.npts = h->npts;
     a.nchunks = h->nchunks;
     a.ngroups = (int)((h->nchunks + G - 1) / G);
@@ -582,22 +597,25 @@ hipError_t nbls_launch_filter_segment(nbls_handle* h, int reverse, const double*
     }
 }
 
-hipError_t nbls_launch_filter(nbls_handle* h) {
+// The channels [ch0, ch0 + nch) of every band (all channels: the usual single launch; a subset: the rows of a trace
+// that is still going up, filtered as they land — identical results, every (band, channel) series is independent).
+hipError_t nbls_launch_filter(nbls_handle* h, int ch0, int nch) {
+    if (ch0 < 0 || nch < 1 || ch0 + nch > h->nchans) return hipErrorInvalidValue;
     if (h->nsections == 0) {
-        hipLaunchKernelGGL(copy_taper_kernel, dim3((unsigned)((h->npts + 255) / 256), h->nchans), dim3(256), 0,
-                           h->stream, h->d_trace, h->d_filt, h->npts_pad, h->npts, h->nchans, h->d_tl, h->d_tr,
-                           h->taper_len);
+        hipLaunchKernelGGL(copy_taper_kernel, dim3((unsigned)((h->npts + 255) / 256), nch), dim3(256), 0,
+                           h->stream, h->d_trace + (size_t)ch0 * h->npts_pad, h->d_filt + (size_t)ch0 * h->npts_pad, h->npts_pad,
+                           h->npts, nch, h->d_tl, h->d_tr, h->taper_len);
         return hipGetLastError();
     }
     switch (h->nsections) {
-        case 1: return run_filter<1>(h);
-        case 2: return run_filter<2>(h);
-        case 3: return run_filter<3>(h);
-        case 4: return run_filter<4>(h);
-        case 5: return run_filter<5>(h);
-        case 6: return run_filter<6>(h);
-        case 7: return run_filter<7>(h);
-        case 8: return run_filter<8>(h);
+        case 1: return run_filter<1>(h, ch0, nch);
+        case 2: return run_filter<2>(h, ch0, nch);
+        case 3: return run_filter<3>(h, ch0, nch);
+        case 4: return run_filter<4>(h, ch0, nch);
+        case 5: return run_filter<5>(h, ch0, nch);
+        case 6: return run_filter<6>(h, ch0, nch);
+        case 7: return run_filter<7>(h, ch0, nch);
+        case 8: return run_filter<8>(h, ch0, nch);
         default: return hipErrorInvalidValue;
     }
 }

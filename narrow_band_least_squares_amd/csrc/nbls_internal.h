@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -36,6 +37,8 @@ struct nbls_options {
     int screen_tb8 = 0;        // 1: the eight-tile instance wherever one lag block per tile step applies (S == 1)
     int screen_batch_mb = 192;  // quantised-window bytes per unit batch
     int solve_min_units = 0;   // > 0: units a per-batch solve (and a streamed result batch) covers at least (default 8192)
+    int filter_row_step = 0;   // > 0: the filter stage runs in launches of at most this many channels even when the whole trace is there
+    int result_tail_units = 0; // streamed pass: the LAST result batch is cut to this many units (0: default 2048, < 0: not cut), see xcorr_screen.hip
     int overlap = 0;           // solve of batch k on a second stream while batch k+1 is correlated: 1 on, -1 off, 0 auto (streamed passes of several small batches)
     int filter_nofuse = 0;     // 1: separate state kernel for the backward filter pass
     int filter_nomfma = 0;     // 1: VALU state kernel
@@ -82,6 +85,14 @@ struct nbls_handle {
     std::string err;
     std::mutex err_mu;                 // fail() may be called from the upload thread (nbls_upload_rows) too
     bool trace_loaded = false;         // samples behind the declared shape (nbls_set_trace_shape / nbls_upload_rows)
+    // The rows of a trace go up on a stream of their own, an event behind each: a pass queued while nbls_upload_rows is
+    // still running on another thread filters the channels as they land (nbls_execute_stages) instead of waiting for the
+    // last one — 16 elements x 24 h at 100 Hz are 1.1 GB = 20 ms over PCIe, the filter of a 12-band share 11 ms.
+    hipStream_t ustream = nullptr;
+    std::vector<hipEvent_t> uev;       // uev[c]: channel c is in HBM
+    hipEvent_t ev_uprev = nullptr;     // what was queued on the compute streams before the upload (it may still read d_trace)
+    std::atomic<int> rows_landed{0};   // channels whose copy is queued and whose event is recorded (published by the upload thread)
+    std::atomic<int> upload_state{0};  // 0 no upload under way, 1 running, 2 shape declared (no samples yet), -1 the upload failed
 
     // ---- trace (HBM resident) ----
     double* d_trace = nullptr;     // [nchans][npts_pad]
@@ -223,7 +234,7 @@ struct nbls_handle {
 };
 
 // Kernel launchers (each returns hipError_t of the launch).
-hipError_t nbls_launch_filter(nbls_handle* h);
+hipError_t nbls_launch_filter(nbls_handle* h, int ch0, int nch);    // channels [ch0, ch0 + nch) of every band
 hipError_t nbls_launch_filter_segment(nbls_handle* h, int reverse, const double* d_init, double* d_fin);
 hipError_t nbls_launch_xcorr(nbls_handle* h);
 hipError_t nbls_launch_solve(nbls_handle* h);

@@ -1689,11 +1689,23 @@ hipError_t nbls_launch_xcorr_screen_range(nbls_handle* h, int64_t ub, int64_t ue
                 (void)hipStreamWaitEvent(h->stream2, h->pev[launches], 0);
                 ss = h->stream2;
             }
-            hipError_t se = nbls_launch_solve_range(h, solve_from, u0 + a.nu - solve_from, ss);
+            // The host trails the GPU by one result batch: what follows the GPU's last kernel is the copy of the LAST batch's
+            // rows and the caller's work on them (the dictionary entries of ~10^4 units: 0.4 ms of a 17 ms call).  The last
+            // batch of a streamed pass is therefore cut in two — its final `tail` units are solved and handed over on their
+            // own, the rows before them travel (and are worked on) while that small solve runs.
+            int64_t tail = h->opt.result_tail_units > 0 ? h->opt.result_tail_units : (h->opt.result_tail_units < 0 ? 0 : 2048);
+            const int64_t send = u0 + a.nu;
+            if (!(h->stream_results && send >= h->nunits && send - solve_from >= 4 * tail)) tail = 0;
+            hipError_t se = nbls_launch_solve_range(h, solve_from, send - tail - solve_from, ss);
             if (se != hipSuccess) return se;
+            if (tail) {
+                if ((se = nbls_queue_result_batch(h, solve_from, send - tail, ss)) != hipSuccess) return se;
+                solve_from = send - tail;
+                if ((se = nbls_launch_solve_range(h, solve_from, tail, ss)) != hipSuccess) return se;
+            }
             if (ev) (void)hipEventRecord(ev[4], ss);
-            if ((se = nbls_queue_result_batch(h, solve_from, u0 + a.nu, ss)) != hipSuccess) return se;
-            solve_from = u0 + a.nu;
+            if ((se = nbls_queue_result_batch(h, solve_from, send, ss)) != hipSuccess) return se;
+            solve_from = send;
         } else if (ev) (void)hipEventRecord(ev[4], h->stream);
         ++launches;
     }

@@ -24,6 +24,9 @@ _handles = {}
 # tools (they were environment variables until round 4: NBLS_UPLOAD_OVERLAP, NBLS_GROUP_ORDER, NBLS_STREAM_PRIORITY,
 # NBLS_PIPELINE_SPLIT, NBLS_KEY_THREADS).  Results never depend on them.
 UPLOAD_OVERLAP = True      # the trace goes up on a helper thread beside the filter design and the plan
+ROW_PIPELINE = True        # ... and the pass is queued while it still does: the library filters the channels as they land
+ROW_PIPELINE_MIN_BYTES = 256 << 20   # ... for traces whose upload is worth hiding (1.1 GB at cfg-4: the 12-band share's call 236 ->
+                           # 221 ms; at cfg-3's 55 MB = 1.2 ms the extra filter launches cost 0.4 ms more than they hide)
 GROUP_ORDER = True         # band groups: the groups' correlation stages are chained on the GPU (nbls_execute_after)
 STREAM_PRIORITY = True     # band groups: earlier groups on higher-priority streams
 PIPELINE_SPLIT = None      # band groups: explicit shares, e.g. (0.15, 0.5, 0.35)
@@ -127,6 +130,11 @@ def stream_rows(st):
             d = np.ascontiguousarray(d, dtype=np.float64)
         rows.append(d)
     return rows, fs, start_datenum(getattr(st[0].stats, 'starttime', 0.0))
+
+
+def row_pipeline_for(nchans, npts):
+    """Queue the pass while the trace is still going up (``Handle.expect_upload``)?  Worth it for long uploads only."""
+    return bool(ROW_PIPELINE) and 8 * int(nchans) * int(npts) >= ROW_PIPELINE_MIN_BYTES
 
 
 def _trace_key(data, fs):
@@ -477,6 +485,7 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     uploader = None
     upload_error = []
     resident = False
+    row_pipeline = False
     if upload and handle is None and (cap >= 1 or prefiltered):
         rk = getattr(get_handle(device, 0), 'resident_key', None)           # engine.resident_trace: these very buffers are in HBM already
         resident = rk is not None and rk == _trace_key(data, fs)
@@ -484,6 +493,9 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
         h0 = get_handle(device, 0)
         up_rows = list(np.ascontiguousarray(data, dtype=np.float64)) if isinstance(data, np.ndarray) else data
         h0.set_trace_shape(nchans, npts, fs)
+        row_pipeline = row_pipeline_for(nchans, npts) and hasattr(h0, 'expect_upload')
+        if row_pipeline:
+            h0.expect_upload()                    # the pass will be queued while the rows are still going up
 
         def _upload():
             try:
@@ -647,10 +659,21 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
             # itself between the passes and all of them land together at the end (stream priorities alone did the
             # job on some boxes and not on others)
             ordered = launched and not sequential and GROUP_ORDER
-            launch(h, data, prep, upload=upload, window_slice=window_slice, uncert=want_uncert,
-                   xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
-                   trace_ready=early, after=launched[-1][0] if ordered else None,
-                   before_execute=upload_done if (early and not resident) else None, stream=streamed)
+            joins = early and not resident               # this launch rides on the upload thread's rows
+            try:
+                launch(h, data, prep, upload=upload, window_slice=window_slice, uncert=want_uncert,
+                       xcorr_impl=xcorr_impl, trace_from=launched[0][0] if (launched and not sequential) else None,
+                       trace_ready=early, after=launched[-1][0] if ordered else None,
+                       before_execute=upload_done if (joins and not row_pipeline) else None, stream=streamed)
+            except BaseException:
+                if joins and uploader is not None:       # the pass could not be queued: the upload's own error is the cause, if it has one
+                    uploader.join()
+                    uploader = None
+                    if upload_error:
+                        raise upload_error[0]
+                raise
+            if joins:
+                upload_done()                            # (row_pipeline: the pass is queued, the library filters the rows as they land)
             launched.append((h, b0, b1))
             res.handle = h
     finally:

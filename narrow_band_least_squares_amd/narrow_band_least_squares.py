@@ -201,9 +201,12 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     # this thread designs the filters of all bands; a pass is planned as soon as the design is there and queued when
     # its GPU's copy has landed
     uploads = []                    # (thread, error list) per local handle
+    row_pipeline = engine.row_pipeline_for(nchans, npts)      # long traces: the passes are queued while the rows still go up
     try:
         for hd in group.handles:
             hd.set_trace_shape(nchans, npts, fs)
+            if row_pipeline and hasattr(hd, 'expect_upload'):
+                hd.expect_upload()
             err = []
 
             def _up(hd=hd, err=err):
@@ -257,8 +260,14 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
             mine = list(range(NBANDS)) if by_windows else shards[r]
             wsl = (r, world) if by_windows else None
             if len(mine) <= cap:
-                engine.launch(hd, rows, prep, bands=None if by_windows else mine, window_slice=wsl, reserve_bytes=block_bytes,
-                              trace_ready=True, before_execute=lambda: landed(i), stream=use_stream)
+                # (queued while the rows may still be going up: the library filters the channels as they land)
+                try:
+                    engine.launch(hd, rows, prep, bands=None if by_windows else mine, window_slice=wsl, reserve_bytes=block_bytes,
+                                  trace_ready=True, before_execute=None if row_pipeline else (lambda: landed(i)), stream=use_stream)
+                except BaseException:
+                    landed(i)                   # the upload's own error is the cause, if it has one
+                    raise
+                landed(i)
                 return
             # the rank's share does not fit the HBM budget of one pass (NBLS_MAX_FILTERED_GB): consecutive passes of
             # <= cap bands, each fetched to the host; the assembled block goes back to the GPU for the ONE gather

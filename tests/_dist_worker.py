@@ -8,6 +8,7 @@ gloo all-gather (process-per-GPU form, this file run under torch.distributed.run
 plain concatenation (one-process form, ``run_single_process`` imported by tests/test_host.py).
 The RCCL gather itself is exercised on the GPU box (tests/test_gpu_parity.py)."""
 import os
+import time
 import sys
 
 import numpy as np
@@ -94,8 +95,11 @@ def make_fake_launch(gold, fail_rank=None, rank_of=None):
             raise ValueError('injected failure on rank %d' % fail_rank)
         if before_execute is not None:       # the real launch joins the upload thread between plan and execute
             before_execute()
-        if trace_ready:                      # the pass works on what the upload thread delivered
-            assert h.uploaded is not None, 'pass queued before the trace had landed'
+        if trace_ready:                      # the pass works on what the upload thread delivers: queued while the rows may
+            t0 = time.time()                 # still be going up, the library waits for them itself (nbls_execute: row events)
+            while h.uploaded is None:
+                assert time.time() - t0 < 30, 'the trace never landed'
+                time.sleep(0.001)
             data = h.uploaded
         idx = list(range(prep.nbands)) if bands is None else list(bands)
         nb, VL, MB, P = len(idx), prep.vector_len, prep.mask_bytes, prep.npairs

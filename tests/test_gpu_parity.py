@@ -709,6 +709,84 @@ def test_two_step_trace_upload_states():
         h.close()
 
 
+def test_pass_queued_while_the_rows_are_still_going_up():
+    """nbls_expect_upload: the pass is planned and queued while nbls_upload_rows runs (or has not even begun) on another
+    thread; the filter stage takes the channels as their events are recorded.  Results equal the one-step form bit for
+    bit — also with the filter forced into launches of one and of three channels on a trace that is there already
+    (option filter_row_step: every (band, channel) series is independent), zero-phase and causal filters; an aborted
+    or failed upload ends the waiting pass with an error at once, and a declared trace nobody announced is refused."""
+    import threading
+    import time
+    from narrow_band_least_squares_amd._hip import Handle, NblsError
+    c = _cfg('cfg2', 0.25)
+    data, fs, t0 = engine.stream_to_array(c['st'])
+    rows = [np.ascontiguousarray(r) for r in data]
+    edges = [(0.3, 0.6), (0.6, 1.2), (1.2, 2.4)]
+    wl = [40.0, 30.0, 20.0]
+    for ftype, alpha in (('butter', 0.5), ('cheby1', 1.0)):
+        prep = engine.prepare(len(rows), len(rows[0]), fs, c['rij'], edges, wl, 0.5, alpha, ftype, 2, 0.01)
+        h = Handle(engine.default_device())
+        try:
+            engine.launch(h, rows, prep)
+            ref = h.fetch_packed()
+            ref_filt = [h.fetch_filtered(b) for b in range(len(edges))]
+            for step in (1, 3):
+                h.set_option('filter_row_step', step)
+                engine.launch(h, rows, prep)
+                out = h.fetch_packed()
+                for k in ref:
+                    np.testing.assert_array_equal(out[k], ref[k])
+                for b in range(len(edges)):
+                    np.testing.assert_array_equal(h.fetch_filtered(b), ref_filt[b])
+            h.set_option('filter_row_step', 0)
+            for delay in (0.0, 0.05):
+                h.set_trace_shape(len(rows), len(rows[0]), fs)
+                h.expect_upload()
+
+                def up():
+                    time.sleep(delay)
+                    h.upload_rows(rows)
+                th = threading.Thread(target=up)
+                th.start()
+                engine.launch(h, rows, prep, trace_ready=True)      # set_geometry, plan, execute: the rows may not be there yet
+                th.join()
+                out = h.fetch_packed()
+                for k in ref:
+                    np.testing.assert_array_equal(out[k], ref[k])
+            # the announced rows never come: the announcing side says so, the pass fails at once
+            h.set_trace_shape(len(rows), len(rows[0]), fs)
+            h.expect_upload()
+            th = threading.Thread(target=lambda: (time.sleep(0.05), h.lib.nbls_abort_upload(h._h)))
+            th.start()
+            t_ = time.perf_counter()
+            with pytest.raises((NblsError, RuntimeError, ValueError)):
+                engine.launch(h, rows, prep, trace_ready=True)
+            th.join()
+            assert time.perf_counter() - t_ < 5.0
+            # rows of the wrong length: refused by upload_rows, which also releases a pass that would wait for them
+            h.set_trace_shape(len(rows), len(rows[0]), fs)
+            h.expect_upload()
+            with pytest.raises(ValueError):
+                h.upload_rows([r[:-1] for r in rows])
+            with pytest.raises((NblsError, RuntimeError, ValueError)):
+                engine.launch(h, rows, prep, trace_ready=True)
+            # declared, not announced: no waiting
+            h.set_trace_shape(len(rows), len(rows[0]), fs)
+            t_ = time.perf_counter()
+            with pytest.raises((NblsError, RuntimeError, ValueError)):
+                engine.launch(h, rows, prep, trace_ready=True)
+            assert time.perf_counter() - t_ < 5.0
+            h.upload_rows(rows)
+            with pytest.raises((NblsError, RuntimeError, ValueError)):
+                h.expect_upload()                                    # (nothing is declared any more: the samples are there)
+            engine.launch(h, rows, prep, trace_ready=True)
+            out = h.fetch_packed()
+            for k in ref:
+                np.testing.assert_array_equal(out[k], ref[k])
+        finally:
+            h.close()
+
+
 def test_upload_error_surfaces_on_the_calling_thread():
     """The helper thread's exception (rows of unequal length) is re-raised by the call, not lost."""
     c = _cfg('cfg2', 0.1)
