@@ -341,7 +341,7 @@ def main():
         prep = engine.prepare(nchans, npts, fs_, rij, [edges[b] for b in my], [winlens[b] for b in my], c['overlap'],
                               c['alpha'], c['ftype'], c['order'], c['ripple'])
         h.set_profiling(True)
-        engine.launch(h, rows, prep, stream=engine.streamed_default())     # (as a whole call runs it: per-batch solves, rows streamed)
+        engine.launch(h, rows, prep, stream=engine.stream_pays(c['alpha'], prep.nwin, prep.npairs))     # (as a whole call runs it: per-batch solves, rows streamed — or one piece)
         h.sync()
         kern, stages = [], []
         for _ in range(steps):

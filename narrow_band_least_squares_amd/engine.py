@@ -87,14 +87,31 @@ def release_deferred():
     del _graveyard[:]
 
 
+STREAM_MIN_UNITS = 16000    # (band, window) units x (pairs / 28) from which a call streams its rows (``stream_pays``)
+
+
 def streamed_default():
-    """Whether a whole call runs as ONE pass whose unit batches stream their rows to the host (``nbls_stream_results``)
-    instead of as several band groups on several handles: the default; ``NBLS_PIPELINE_GROUPS`` > 1 selects the band
-    groups of rounds 2-3, ``NBLS_STREAM_RESULTS=0`` one group without streaming."""
+    """Whether ``NBLS_STREAM_RESULTS`` / ``NBLS_PIPELINE_GROUPS`` allow the streamed form at all (see ``stream_pays``)."""
     if os.environ.get('NBLS_STREAM_RESULTS', '1') == '0':
         return False
     env = os.environ.get('NBLS_PIPELINE_GROUPS')
     return not (env and int(env) > 1)
+
+
+def stream_pays(alpha, nwin, npairs=28):
+    """Whether a whole call runs as ONE pass whose unit batches stream their rows to the host (``nbls_stream_results``)
+    while the GPU works on the next batch.  What the host does with a batch's rows is the dropped-element dictionary, so:
+    under LTS, from ``STREAM_MIN_UNITS`` units on (weighted by the pair count as in ``pipeline_groups``).  Below that, and
+    under OLS (no dictionary), the pass is fetched in one piece: the per-batch solves, copies and events of the streamed
+    form are pure overhead there (cfg-1b, 443 OLS units in 8 window groups: 2.2 ms per call streamed, 1.07 ms in one piece;
+    cfg-2, 5 700 LTS units: no difference; cfg-3: 17.1 against 18.5 ms).  ``NBLS_STREAM_RESULTS=1`` streams always, ``=0``
+    never; ``NBLS_PIPELINE_GROUPS`` > 1 selects the band groups of rounds 2-3."""
+    if not streamed_default():
+        return False
+    if os.environ.get('NBLS_STREAM_RESULTS') == '1':
+        return True
+    weight = max(1.0, float(npairs) / 28.0)
+    return float(alpha) < 1.0 and int(np.sum(nwin) * weight) >= STREAM_MIN_UNITS
 
 
 def stream_to_array(st):
@@ -525,8 +542,9 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
                                      filter_ripple, vector_len, device, xcorr_impl, want_lag, want_cmax, want_z, host_overlap,
                                      group_done)
         cap = max(1, cap)
-        streamed = groups is None and window_slice is None and streamed_default()
-        ngroups = 1 if ((prefiltered or handle is not None or not upload) and groups is None) or streamed else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))
+        streamed = groups is None and window_slice is None and stream_pays(alpha, nwin, nchans * (nchans - 1) // 2)
+        one_pass = (prefiltered or handle is not None or not upload or (alpha >= 1.0 and not os.environ.get('NBLS_PIPELINE_GROUPS'))) and groups is None
+        ngroups = 1 if one_pass or streamed else (groups or pipeline_groups(nwin, nchans * (nchans - 1) // 2))     # (OLS: nothing for the host to do per group)
         ngroups = max(1, min(ngroups, nb))
         # contiguous band groups by unit count.  engine.PIPELINE_SPLIT = (0.15, 0.5, 0.35): explicit shares (a small first
         # group gets the GPU started sooner, a small last group leaves less dictionary work after the GPU has finished)

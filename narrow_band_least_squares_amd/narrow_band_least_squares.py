@@ -252,7 +252,7 @@ def narrow_band_least_squares_parallel(WINLEN_list, WINOVER, ALPHA, st, lat_list
     if status == 0:
         cap = max(1, engine.max_bands_per_pass(nchans, npts))      # filtered bands one pass may keep in HBM
         use_stream = (not by_windows and ALPHA < 1.0 and contiguous
-                      and engine.streamed_default() and max(len(sh) for sh in shards) <= cap
+                      and engine.stream_pays(ALPHA, prep.nwin, npairs) and max(len(sh) for sh in shards) <= cap
                       and all(hasattr(hd, 'wait_result_batch') for hd in group.handles))
 
         def start(i, hd):

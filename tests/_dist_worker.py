@@ -210,7 +210,7 @@ def run_single_process(gold_name, mode, world, monkeypatch, bands_per_pass=None)
     nb = call_and_compare(gold, group)
     if bands_per_pass:
         assert any(getattr(h, 'loaded', False) and h.rounds >= 2 for h in group.handles), 'no rank needed several rounds'
-    elif mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS', '1') != '0':
+    elif mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS') == '1':
         # contiguous band shares under LTS: the dictionary was built from the ranks' streamed batches, in rank order
         assert all(h.streamed and h.waited == h.result_batches() for h in group.handles if h.block is not None), 'not streamed'
     else:
@@ -235,7 +235,7 @@ def main():
             raise RuntimeError('injected failure before planning on rank 1')
         group.handles[0].set_trace_shape = boom
     nb = call_and_compare(gold, group, expect_failure=mode in ('fail', 'fail_early'))
-    if mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS', '1') != '0':
+    if mode == 'bands' and float(gold['alpha']) < 1.0 and os.environ.get('NBLS_STREAM_RESULTS') == '1':
         # under a launcher too, a rank builds the dictionary entries of ITS bands from its streamed batches (rank 0 straight
         # into the result, rank 1 into a part merged behind rank 0's gathered entries); the key order is checked above
         hd = group.handles[0]

@@ -275,7 +275,7 @@ def test_partner_groups_extend_the_screening_correlator_to_long_windows(nchans, 
     np.testing.assert_array_equal(got.baz, ref.baz)
 
 
-def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
+def test_adaptive_windows_choose_the_correlator_per_window_length(oracle, monkeypatch):
     """example.py's adaptive windows 60 -> 30 s at 100 Hz in ONE call, plus a 140 s band (W = 14 000: beyond what the
     screening kernel can hold even with four copies and two partners per group, ~13 000): every band of a screenable
     window length is screened, only the 140 s band runs on the general correlator (windows read from global memory:
@@ -309,6 +309,7 @@ def test_adaptive_windows_choose_the_correlator_per_window_length(oracle):
     # correlator was never solved — all-zero rows with rc OK.  Same rows now, whichever way the solves are scheduled.
     ref_rows = {k: getattr(got, k).copy() for k in ('vel', 'baz', 'mdccm', 'sigma_tau', 'lag')}
     r0 = rij - rij.mean(axis=1, keepdims=True)
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '1')      # (calls without `groups` below are streamed passes; by itself a call of this size is not)
     for alpha in (1.0, 0.5):
         base = engine.process(data, fs, 17884.0729166667, r0, edges, winlens, 0.5, alpha, 'butter', 2, 0.01, want_lag=True, want_z=True, groups=1)
         if alpha == 1.0:

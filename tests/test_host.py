@@ -162,6 +162,7 @@ def test_sharded_path_one_process_many_devices(gold, mode, world, monkeypatch):
     per-device launch threads, gather to root 0) with oracle-backed stand-ins for the device pass."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import _dist_worker
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '1')        # (goldens are small: left to itself a call of this size is not streamed)
     assert _dist_worker.run_single_process(gold, mode, world, monkeypatch) >= 1
 
 
@@ -179,13 +180,37 @@ def test_sharded_path_runs_a_share_in_hbm_rounds(gold, mode, world, monkeypatch)
                                        ('loop_ols_butter_linear', 'windows'), ('loop_lts_butter_octave', 'windows'),
                                        ('loop_lts_butter_octave', 'fail'), ('loop_lts_butter_octave', 'fail_early')])
 def test_band_sharded_path_world_size_2_gloo(gold, mode):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', NBLS_STREAM_RESULTS='1')    # (streamed although the goldens are small)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', '29533',
            os.path.join(ROOT, 'tests', '_dist_worker.py'), gold, mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=2' in r.stdout
+
+
+def test_trace_identity_and_row_pipeline_threshold(monkeypatch):
+    """Host logic of the two upload shortcuts: a resident trace is recognised by WHERE its samples lie (same buffers, same
+    sampling rate — a copy, a float32 or strided row is not "the same trace"), and a pass is queued on rows that are still
+    going up only for traces whose upload is worth hiding."""
+    from narrow_band_least_squares_amd import engine
+    rows = [np.zeros(1000) for _ in range(4)]
+    k = engine._trace_key(rows, 20.0)
+    assert k is not None and k == engine._trace_key(list(rows), 20.0)
+    assert k != engine._trace_key(rows, 40.0)
+    assert k != engine._trace_key([r.copy() for r in rows], 20.0)
+    assert k != engine._trace_key(rows[:3], 20.0)
+    assert engine._trace_key([r.astype(np.float32) for r in rows], 20.0) is None
+    assert engine._trace_key([np.zeros(2000)[::2] for _ in range(4)], 20.0) is None
+    block = np.zeros((4, 1000))
+    assert engine._trace_key(block, 20.0) == engine._trace_key(block, 20.0) != engine._trace_key(block.copy(), 20.0)
+    assert not engine.row_pipeline_for(8, 864000)                 # cfg-3: 55 MB
+    assert engine.row_pipeline_for(16, 8640000)                   # cfg-4: 1.1 GB
+    monkeypatch.setattr(engine, 'ROW_PIPELINE', False)
+    assert not engine.row_pipeline_for(16, 8640000)
+    monkeypatch.setattr(engine, 'ROW_PIPELINE', True)
+    monkeypatch.setattr(engine, 'ROW_PIPELINE_MIN_BYTES', 0)
+    assert engine.row_pipeline_for(3, 100)
 
 
 def test_confidence_intervals_against_brute_force(oracle):
@@ -336,6 +361,7 @@ def test_streamed_pass_builds_rows_and_dictionary_batch_by_batch(monkeypatch):
     c = synthetic.build_config('cfg2', 0.1)
     nb = 5
     rng = np.random.default_rng(11)
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '1')        # (a call of this size is not streamed by itself: engine.stream_pays)
 
     class StubHandle:
         def set_trace_shape(self, *a): pass
@@ -434,6 +460,19 @@ def test_streamed_pass_builds_rows_and_dictionary_batch_by_batch(monkeypatch):
     out2 = narrow_band_least_squares(*args, rij=c['rij'])
     assert not hstub.streamed and not waited
     np.testing.assert_array_equal(out2[0], hstub.out['vel'])
+    # left to itself (engine.stream_pays): a call of 10^3 units is fetched in one piece, LTS or not; streaming starts where
+    # the dictionary work of a batch is worth overlapping
+    monkeypatch.delenv('NBLS_STREAM_RESULTS')
+    monkeypatch.delenv('NBLS_PIPELINE_GROUPS')
+    del waited[:]
+    narrow_band_least_squares(*args, rij=c['rij'])
+    assert not hstub.streamed and not waited
+    assert engine.stream_pays(0.5, [40000]) and engine.stream_pays(0.5, [1000], npairs=496) and not engine.stream_pays(1.0, [40000])
+    assert not engine.stream_pays(0.5, [15999]) and engine.stream_pays(0.5, [8000, 8000])
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '1')
+    assert engine.stream_pays(1.0, [10])
+    monkeypatch.setenv('NBLS_STREAM_RESULTS', '0')
+    assert not engine.stream_pays(0.5, [40000])
 
 
 def test_bench_refuses_what_it_cannot_measure():
