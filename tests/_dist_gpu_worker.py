@@ -68,9 +68,16 @@ def main():
         return
     # (the fourth case: an HBM budget of two bands per pass — the share runs in three rounds, the block assembled on the
     #  host goes back through nbls_load_result_block and out through the same gather)
-    for name, alpha, shard, per_pass in (('cfg1', 1.0, 'bands', 0), ('cfg2', 0.5, 'bands', 0), ('cfg2', 0.75, 'windows', 0),
-                                         ('cfg2', 0.5, 'bands', 2)):
+    # (stream: NBLS_STREAM_RESULTS — '1' = the dictionary from the ranks' streamed batches although the call is small, None = as
+    #  a call of this size runs by itself, in one piece; rows: the passes are queued while their traces are still going up)
+    for name, alpha, shard, per_pass, stream, rows_in_flight in (('cfg1', 1.0, 'bands', 0, None, False), ('cfg2', 0.5, 'bands', 0, '1', True),
+                                                                 ('cfg2', 0.5, 'bands', 0, None, False), ('cfg2', 0.75, 'windows', 0, '1', True),
+                                                                 ('cfg2', 0.5, 'bands', 2, None, False)):
         os.environ['NBLS_SHARD'] = shard
+        os.environ.pop('NBLS_STREAM_RESULTS', None)
+        if stream:
+            os.environ['NBLS_STREAM_RESULTS'] = stream
+        engine.ROW_PIPELINE_MIN_BYTES = 0 if rows_in_flight else 256 << 20
         c = synthetic.build_config(name, 0.1)
         nb = 9 if mode == 'loop8' else 5             # (eight ranks: some take two bands, most one)
         os.environ.pop('NBLS_MAX_FILTERED_GB', None)
@@ -84,6 +91,8 @@ def main():
                 fr, 'butter', 2, 0.01)
         par = narrow_band_least_squares_parallel(*args, rij=c['rij'])
         os.environ.pop('NBLS_MAX_FILTERED_GB', None)
+        os.environ.pop('NBLS_STREAM_RESULTS', None)
+        engine.ROW_PIPELINE_MIN_BYTES = 256 << 20
         ser = narrow_band_least_squares(*args, rij=c['rij'])
         assert par[6] == ser[6]
         for i in (0, 1, 2, 3, 5, 7, 8):
