@@ -487,8 +487,8 @@ def process(data, fs, t0_datenum, rij, band_edges, winlens, winover, alpha, filt
     later groups are still being computed (the caller builds its dictionary there).
     More bands than fit in HBM at once are processed in consecutive rounds.
 
-    Default since round 4 (``streamed_default``; ``groups`` given or ``NBLS_PIPELINE_GROUPS`` > 1 select the band groups
-    above): ONE pass on one handle whose unit batches — consecutive (band, window) units, each a complete
+    Round 4, where it pays (``stream_pays``: LTS calls of 16 000 units and more; ``groups`` given or ``NBLS_PIPELINE_GROUPS`` > 1
+    select the band groups above, smaller and OLS calls are one pass fetched in one piece): ONE pass on one handle whose unit batches — consecutive (band, window) units, each a complete
     correlate -> solve -> pack chain on the GPU — copy their rows into a pinned host mirror as they finish
     (``nbls_stream_results``).  ``units_done(res, u0, u1)`` runs as soon as the rows of the units [u0, u1) (flat index
     over all bands of the call, band-major) are in ``res``, while the GPU works on the next batch; without it
