@@ -49,17 +49,28 @@ RESIDENT = 'resident' in sys.argv[2:]     # the calls run inside `with engine.re
 kept = []
 ctx = engine.resident_trace(c['st']) if RESIDENT else contextlib.nullcontext()
 ctx.__enter__()
-for rep in range(12 if HOLD else 6):
+allev, totals = [], []
+for rep in range(16 if HOLD else 6):
     planner.design_cache_clear()
     events.clear()
     T0[0] = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         out = narrow_band_least_squares(*args, rij=c['rij'])
     total = (time.perf_counter() - T0[0]) * 1e3
+    totals.append(total)
+    allev.append(sorted(events, key=lambda e: e[1]))
     if HOLD:
         kept.append(out)
     del out
 ctx.__exit__(None, None, None)
-print('whole call %.2f ms%s' % (total, ' (trace resident)' if RESIDENT else ''))
-for label, a, b in sorted(events, key=lambda e: e[1]):
+print('whole call %.2f ms%s (last of %d; median of the last %d: %.2f)' % (total, ' (trace resident)' if RESIDENT else '', len(totals), len(totals) - 4, np.median(totals[4:])))
+for label, a, b in allev[-1]:
     print('  %6.2f .. %6.2f  (%5.2f)  %s' % (a, b, b - a, label))
+# the same events over the calls after the first four (same sequence of labels in every call): medians
+seq = [e[0] for e in allev[-1]]
+rest = [ev for ev in allev[4:] if [e[0] for e in ev] == seq]
+if len(rest) > 2:
+    print('medians over %d calls:' % len(rest))
+    for i, label in enumerate(seq):
+        a = np.median([ev[i][1] for ev in rest]); b = np.median([ev[i][2] for ev in rest])
+        print('  %6.2f .. %6.2f  (%5.2f)  %s' % (a, b, np.median([ev[i][2] - ev[i][1] for ev in rest]), label))
