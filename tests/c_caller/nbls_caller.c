@@ -11,11 +11,24 @@
  * quantile, zero_scale.
  * Output: double vel, baz, mdccm, sigma_tau [nbands][vector_len], int32 nwin[nbands],
  * int32 lag[nbands][vector_len][npairs], uint8 weights[nbands][vector_len][npairs]. */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include "nbls.h"
+
+/* the rows of a trace uploaded by another thread, a moment after the pass was announced (nbls_expect_upload) */
+struct upload_job { nbls_handle* h; const double* const* rows; int32_t nchans; int64_t npts; int rc; };
+static void* upload_later(void* p) {
+    struct upload_job* j = p;
+    const struct timespec ts = {0, 2000000};      /* 2 ms: the other thread is planning, or already waiting in nbls_execute */
+    nanosleep(&ts, NULL);
+    j->rc = nbls_upload_rows(j->h, j->rows, j->nchans, j->npts);
+    return NULL;
+}
 
 static void rd(void* p, size_t n, FILE* f) {
     if (n && fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
@@ -96,6 +109,22 @@ int main(int argc, char** argv) {
         if ((rc = nbls_upload_rows(h, rows, nchans, npts)) || (rc = nbls_execute(h))) {
             fprintf(stderr, "upload / execute: %d %s\n", rc, nbls_last_error(h));
             return 1;
+        }
+        /* the announced form: the pass is planned AND queued while another thread is still uploading the rows — the
+         * filter stage takes the channels as they land (same results: checked against nbls_run below) */
+        {
+            struct upload_job job = {h, rows, nchans, npts, -1};
+            pthread_t th;
+            if ((rc = nbls_set_trace_shape(h, nchans, npts, fs)) || (rc = nbls_expect_upload(h))) {
+                fprintf(stderr, "announce: %d %s\n", rc, nbls_last_error(h));
+                return 1;
+            }
+            if (nbls_expect_upload(h) != NBLS_ERR_STATE) { fprintf(stderr, "a second announcement must be NBLS_ERR_STATE\n"); return 1; }
+            if (pthread_create(&th, NULL, upload_later, &job)) { fprintf(stderr, "pthread_create\n"); return 1; }
+            rc = nbls_plan(h, 1, S ? sos : NULL, S, zero_phase, tl, tr, tl_n, winlen, wininc, VL, lts_flag ? &lp : NULL, 0);
+            if (!rc) rc = nbls_execute(h);
+            pthread_join(th, NULL);
+            if (rc || job.rc) { fprintf(stderr, "pass on rows in flight: %d / upload %d: %s\n", rc, job.rc, nbls_last_error(h)); return 1; }
         }
         if ((rc = nbls_set_trace_from(h2, h)) || (rc = nbls_set_geometry(h2, xij, pair, xpinv, P)) ||
             (rc = nbls_plan(h2, B - 1, S ? sos + (size_t)S * 6 : NULL, S, zero_phase, tl, tr, tl_n, winlen + 1, wininc + 1, VL,

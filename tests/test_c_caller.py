@@ -18,7 +18,7 @@ LIBDIR = os.path.join(ROOT, 'narrow_band_least_squares_amd', 'csrc')
 
 
 def build_caller():
-    cmd = ['gcc', '-O1', '-Wall', '-Wextra', '-Werror', '-std=c11', '-I', os.path.join(ROOT, 'include'),
+    cmd = ['gcc', '-O1', '-Wall', '-Wextra', '-Werror', '-std=c11', '-pthread', '-I', os.path.join(ROOT, 'include'),
            os.path.join(CDIR, 'nbls_caller.c'), '-o', BIN, '-L', LIBDIR, '-lnbls_hip',
            '-Wl,-rpath,$ORIGIN/../../narrow_band_least_squares_amd/csrc', '-Wl,-rpath-link,/opt/rocm/lib']
     r = subprocess.run(cmd, capture_output=True, text=True)
